@@ -1,0 +1,267 @@
+"""CPU: the numpy oracle against golden vectors captured from the reference.
+
+This is what pins the oracle.  Tolerances: forward 1e-4 relative (north_star), gradients
+1e-3; both sides are float32 (reference: torch/oneDNN, oracle: numpy), so the observed gaps
+are ~1e-6 and the bounds below are far tighter than north_star requires.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import timeband_oracle as O
+
+SCEN = ["cfg1", "uneven", "twolayer"]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def sub(z, prefix):
+    prefix = prefix + "."
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def assert_grads_close(got, want, tol, what):
+    """Per tensor: max|got-want| <= tol*max|want| + 0.1*tol*(largest |grad| of the whole net).
+    The second term covers tensors whose value is the residue of a cancelling sum (e.g. the
+    WGAN critic's bias gradient = mean over real minus mean over fake), where float32
+    summation order alone moves the result by ~1e-3 of its own tiny magnitude."""
+    assert set(got) == set(want), what
+    gmax = max(np.abs(v).max() for v in want.values())
+    for k in want:
+        err = np.abs(np.asarray(got[k], np.float64) - want[k]).max()
+        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
+
+
+def assert_params_close(params, want, step, what):
+    """After an Adam step every element moves by ~lr*g/(|g|+eps): where |g| ~ eps = 1e-8 the
+    update is ill-conditioned in ANY float32 implementation (its sign can flip), so a tiny
+    fraction of elements may differ by up to 2 steps; all others must agree to 5 % of a step."""
+    nbad = ntot = 0
+    for k in want:
+        d = np.abs(np.asarray(params[k], np.float64) - want[k])
+        assert d.max() <= 2.1 * step, (what, k, d.max())
+        nbad += int((d > 0.05 * step).sum())
+        ntot += d.size
+    assert nbad / ntot < 1e-3, (what, nbad, ntot)
+
+
+@pytest.mark.parametrize("name", SCEN)
+def test_forward(golden_dir, name):
+    z = load(golden_dir, f"scenario_{name}.npz")
+    V, E, To, Tf, H, L, B = z["meta"]
+    pD, pG = sub(z, "init.netD"), sub(z, "init.netG")
+    Gx, _ = O.generator_fwd(pG, z["x"], L)
+    Dy, _ = O.discriminator_fwd(pD, z["y"], L)
+    DGx, _ = O.discriminator_fwd(pD, Gx, L)
+    assert Gx.shape == (B, Tf, V) and Dy.shape == (B, Tf, 1)
+    assert relerr(Gx, z["fwd.Gx"]) < 1e-5
+    assert relerr(Dy, z["fwd.Dy"]) < 1e-5
+    assert relerr(DGx, z["fwd.DGx"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", SCEN)
+def test_losses(golden_dir, name):
+    z = load(golden_dir, f"scenario_{name}.npz")
+    y, Gx, Dy, DGx = z["y"], z["fwd.Gx"], z["fwd.Dy"], z["fwd.DGx"]
+    L = O.Losses(50, 50, 50)
+    assert relerr(L.dis_loss(y, Gx, Dy, DGx)[0], z["loss.dis"]) < 1e-5
+    assert relerr(L.dis_loss(y, Gx, Dy, DGx, critic=True)[0], z["loss.dis_critic"]) < 1e-5
+    assert relerr(L.gen_loss(y, Gx, DGx)[0], z["loss.gen"]) < 1e-5
+    assert relerr(O.gan_loss(DGx, False)[0], z["loss.gan_fake"]) < 1e-5
+    assert relerr(O.gan_loss(Dy, True)[0], z["loss.gan_real"]) < 1e-5
+    l1, l2, gp, _, _ = O.recon_terms(y, Gx, 50, 50, 50)
+    assert relerr(l1, z["loss.l1"]) < 1e-5
+    assert relerr(l2, z["loss.l2"]) < 1e-5
+    assert relerr(gp, z["loss.gp"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", SCEN)
+def test_iteration_grads_and_steps(golden_dir, name):
+    """trainer.py:142-194: critic grads + RMSprop step, D-phase grads (D and, through the
+    non-detached fake_y, G) + Adam(D), G-phase accumulated grads + Adam(G)."""
+    z = load(golden_dir, f"scenario_{name}.npz")
+    V, E, To, Tf, H, L, B = z["meta"]
+    st = O.TrainState(sub(z, "init.netD"), sub(z, "init.netG"), n_layers=int(L), lr=float(z["lr"]))
+    rec = {}
+    fake = O.train_iteration(st, z["x"], z["y"], z["xc"], z["yc"], rec=rec)
+    assert relerr(rec["critic.errD"], z["it0.critic.errD"]) < 1e-5
+    assert_grads_close(rec["critic.grad.netD"], sub(z, "it0.critic.grad.netD"), 1e-3, "critic grad D")
+    assert relerr(rec["dphase.errD"], z["it0.dphase.errD"]) < 1e-5
+    assert_grads_close(rec["dphase.grad.netD"], sub(z, "it0.dphase.grad.netD"), 1e-4, "dphase grad D")
+    assert_grads_close(rec["dphase.grad.netG"], sub(z, "it0.dphase.grad.netG"), 1e-3, "dphase grad G")
+    assert relerr(rec["gphase.errG"], z["it0.gphase.errG"]) < 1e-5
+    assert_grads_close(rec["gphase.grad.netG"], sub(z, "it0.gphase.grad.netG"), 1e-4, "gphase grad G")
+    assert relerr(fake, z["it0.fake_y"]) < 1e-5
+    # parameters after the steps: |update| is ~lr (Adam) or ~10 lr (fresh RMSprop) per element,
+    # so compare the UPDATE, allowing sign flips only where the gradient is numerically zero
+    lr = float(z["lr"])
+    for tag, params, init in (("it0.dphase.after.netD", st.pD, None), ("it0.gphase.after.netG", st.pG, None)):
+        want = sub(z, tag)
+        assert_params_close(params, want, lr, tag)
+    if name == "cfg1":
+        return
+    # two more iterations: Adam moments carry over, RMSprop is fresh per batch
+    for it in (1, 2):
+        rec = {}
+        O.train_iteration(st, z[f"it{it}.x"], z[f"it{it}.y"], z[f"it{it}.xc"], z[f"it{it}.yc"], rec=rec)
+        assert relerr(rec["critic.errD"], z[f"it{it}.critic.errD"]) < 1e-4
+        assert relerr(rec["dphase.errD"], z[f"it{it}.dphase.errD"]) < 1e-4
+        assert relerr(rec["gphase.errG"], z[f"it{it}.gphase.errG"]) < 1e-4
+    for tag, params in (("it2.dphase.after.netD", st.pD), ("it2.gphase.after.netG", st.pG)):
+        want = sub(z, tag)
+        assert_params_close(params, want, lr, tag)
+
+
+def test_critic_rmsprop_step(golden_dir):
+    z = load(golden_dir, "scenario_uneven.npz")
+    V, E, To, Tf, H, L, B = z["meta"]
+    st = O.TrainState(sub(z, "init.netD"), sub(z, "init.netG"), n_layers=int(L), lr=float(z["lr"]))
+    O.critic_step(st, z["xc"], z["yc"])
+    want = sub(z, "it0.critic.after.netD")
+    g = sub(z, "it0.critic.grad.netD")
+    for k in want:
+        # fresh RMSprop: update = -lr * g / (0.1|g| + 1e-8); elements with |g| ~ 1e-8 are
+        # ill-conditioned in ANY fp32 implementation, so they are excluded
+        ok = np.abs(g[k]) > 1e-6
+        assert np.abs(st.pD[k] - want[k])[ok].max() < 0.05 * 10 * float(z["lr"]), k
+
+
+def test_band_three_classes(golden_dir):
+    z = load(golden_dir, "band_adjust.npz")
+    Tf, V = z["meta"]
+    for cname in ("trainer", "cleaner", "predictor"):
+        band = O.Band(int(Tf), int(V), float(z["band_width"]))
+        for i in range(4):
+            p, lo, up = band.predicts(z[f"band.pred{i}"])
+            np.testing.assert_allclose(p, z[f"band.{cname}.preds{i}"], rtol=0, atol=0)
+            np.testing.assert_allclose(lo, z[f"band.{cname}.lower{i}"], rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(up, z[f"band.{cname}.upper{i}"], rtol=1e-13, atol=1e-13)
+            np.testing.assert_array_equal(np.isnan(band.preds), np.isnan(z[f"band.{cname}.state{i}"]))
+    for tag, Tf2, V2, w, n in (("band2", 2, 2, 1.0, 3), ("band6", 6, 2, 2.0, 4)):
+        band = O.Band(Tf2, V2, w)
+        for i in range(n):
+            p, lo, up = band.predicts(z[f"{tag}.pred{i}"])
+            np.testing.assert_allclose(p, z[f"{tag}.preds{i}"], rtol=0, atol=0)
+            np.testing.assert_allclose(lo, z[f"{tag}.lower{i}"], rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(up, z[f"{tag}.upper{i}"], rtol=1e-13, atol=1e-13)
+
+
+def test_adjust_three_variants(golden_dir):
+    z = load(golden_dir, "band_adjust.npz")
+    for cname in ("trainer", "cleaner", "predictor"):
+        out = z["adj.output"].copy()
+        tgt = O.adjust(cname, out, z["adj.preds"], z["adj.masks"], z["adj.lower"], z["adj.upper"],
+                       float(z["adj.a"]), float(z["adj.b"]))
+        np.testing.assert_allclose(tgt, z[f"adj.{cname}.target"], rtol=1e-14, atol=0)
+    # the three variants genuinely differ on this input
+    assert not np.allclose(z["adj.trainer.target"], z["adj.cleaner.target"])
+    assert not np.allclose(z["adj.cleaner.target"], z["adj.predictor.target"])
+
+
+def test_metric(golden_dir):
+    z = load(golden_dir, "metric.npz")
+    for i in range(3):
+        nme, nmae, rmse = O.metrics(z[f"true{i}"], z[f"pred{i}"], z[f"mask{i}"])
+        np.testing.assert_allclose(nme, z[f"nme{i}"], rtol=1e-12)
+        np.testing.assert_allclose(nmae, z[f"nmae{i}"], rtol=1e-12)
+        np.testing.assert_allclose(rmse, z[f"rmse{i}"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------
+# dataset pipeline + one full epoch + clean/predict (pipeline.npz)
+# ---------------------------------------------------------------------------------------
+def make_series(z):
+    from timeband_amd import synthetic
+    V, To, Tf, H, L, B, N = (int(v) for v in z["meta"])
+    values = synthetic.make_series(N, V, seed=31)
+    tfeat = synthetic.time_features(N + Tf)
+    return O.SeriesData(values, tfeat, To, Tf, split_rate=0.8), (V, To, Tf, H, L, B, N)
+
+
+def test_dataset_pipeline(golden_dir):
+    z = load(golden_dir, "pipeline.npz")
+    s, (V, To, Tf, H, L, B, N) = make_series(z)
+    assert list(z["ds.columns"]) == ["hour", "weekday", "day", "month", "v0", "v1", "v2"]
+    assert s.data_length == int(z["ds.data_length"]) == N + Tf
+    # pandas' default csv float parser is not round-trip exact: ~1e-16 absolute noise
+    np.testing.assert_allclose(s.original, z["ds.original"], rtol=1e-12, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(s.norm, z["ds.normalized"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(s.observed, z["ds.observed"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(s.forecast, z["ds.forecast"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(s.missing, z["ds.missing"])
+    np.testing.assert_allclose(s.decode_min, z["ds.decode_min"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(s.decode_max, z["ds.decode_max"], rtol=1e-12, atol=1e-15)
+    enc, dec = O.windowing(s.norm, s.target_cols, To, Tf)
+    k = O.split_index(s.data_length, To, Tf, 0.8, 2)
+    assert k == int(z["ds.train_len"]) and len(enc) - k == int(z["ds.valid_len"])
+    assert len(enc) == int(z["full_len"])
+    np.testing.assert_allclose(enc[0], z["ds.win0.encoded"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dec[0], z["ds.win0.decoded"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(enc[-1], z["ds.winlast.encoded"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dec[-1], z["ds.winlast.decoded"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.fixture(scope="module")
+def trained(golden_dir):
+    """One Gen-A epoch with the oracle (train pass then valid pass), as trainer.py:87-123."""
+    z = load(golden_dir, "pipeline.npz")
+    s, (V, To, Tf, H, L, B, N) = make_series(z)
+    enc, dec = O.windowing(s.norm, s.target_cols, To, Tf)
+    k = O.split_index(s.data_length, To, Tf, 0.8, 2)
+    s._train_windows = (enc[:k], dec[:k])
+    st = O.TrainState(sub(z, "init.netD"), sub(z, "init.netG"), n_layers=L, lr=2e-4)
+    pp = O.PostProcess(s, "trainer", 1.0, 0.2, 0.3)
+    rng = np.random.RandomState(31)          # seeding(31) -> np.random.seed(31); first draw is get_random
+    res = {}
+    res["train"] = O.train_epoch_pass(st, s, pp, enc[:k], dec[:k], B, True, rng, k)
+    res["train.losses"] = st.losses.loss(res["train"][2] - 1)
+    res["train.band"] = pp.band.preds.copy()
+    res["pD"], res["pG"] = dict(st.pD), dict(st.pG)
+    res["valid"] = O.train_epoch_pass(st, s, pp, enc[k:], dec[k:], B, False, rng, k)
+    res["valid.losses"] = st.losses.loss(res["valid"][2] - 1)
+    return z, s, st, res, (V, To, Tf, H, L, B, N)
+
+
+def test_epoch_matches_reference(trained):
+    z, s, st, res, _ = trained
+    # 10 training iterations of Adam/RMSprop: parameters agree to a small fraction of the total drift
+    for tag, params in (("ep0.train.netD", res["pD"]), ("ep0.train.netG", res["pG"])):
+        want = sub(z, tag)
+        init = sub(z, "init." + tag.split(".")[-1])
+        for kk in want:
+            drift = np.abs(want[kk] - init[kk]).max()
+            bad = np.abs(params[kk] - want[kk]) > 0.02 * drift + 1e-7
+            assert bad.mean() < 2e-3, (tag, kk, bad.mean())
+    # loss running means as printed by the reference (3 decimals)
+    keys = ("D", "R", "F", "G", "G_", "L1", "L2", "GP")
+    for phase in ("train", "valid"):
+        want = [float(v) for v in z[f"ep0.{phase}.losses"]]
+        got = [float(res[f"{phase}.losses"][k]) for k in keys]
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3)
+        nme, nmae, rmse = res[phase][1]
+        w = [float(v) for v in z[f"ep0.{phase}.scores"]]
+        np.testing.assert_allclose([nme, nmae, rmse], w, rtol=5e-3, atol=2e-3)
+        np.testing.assert_allclose(res[phase][0], float(z[f"ep0.{phase}.score"]), rtol=5e-3)
+
+
+def test_clean_and_predict(trained):
+    """cleaner.py:55-128 / predictor.py:56-104 with the REFERENCE's trained weights, so the
+    check isolates the inference + band + adjust path."""
+    z, s, st, res, (V, To, Tf, H, L, B, N) = trained
+    pG = sub(z, "ep0.train.netG")
+    out, lo, up = O.clean(pG, s, B, L, "cleaner", 1.0, 0.2, 0.3)
+    assert out.shape == z["clean.outputs"].shape == (N + Tf, V)
+    np.testing.assert_allclose(out, z["clean.outputs"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([lo, up], axis=1), z["clean.bands"], rtol=2e-4, atol=2e-4)
+    out2, _, _ = O.clean(pG, s, B, L, "predictor", 1.0, 0.2, 0.3)
+    np.testing.assert_allclose(out2, z["predict.outputs"], rtol=2e-4, atol=2e-5)
