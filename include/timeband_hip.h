@@ -1,0 +1,125 @@
+/* timeband_hip.h -- C-ABI of libtimeband_hip.so: the gfx950 (MI355X) kernels behind Timeband's
+ * LSTM-GAN training / cleaning hot path.
+ *
+ * The reference (handal95/Timeband) has no FFI of its own: its hot path is torch library ops called
+ * from Python.  Each entry point below names the reference call site (file:line under
+ * /root/reference) whose torch op(s) it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - tensors are dense, row-major, float32 unless typed otherwise;
+ *   - `stream` is a hipStream_t (void*); work is enqueued, never synchronised;
+ *   - the library allocates nothing on the device: callers pass workspaces sized by the
+ *     matching *_workspace_bytes() query;
+ *   - return value 0 = ok; otherwise tb_last_error() (host string, thread-local) says why.
+ */
+#ifndef TIMEBAND_HIP_H
+#define TIMEBAND_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------ */
+int tb_version(void);
+const char* tb_last_error(void);
+/* Select `device`, check it is gfx950, cache its CU count.  Mirrors init_device
+ * (source/utils/initiate.py:21-28), one process per GPU. */
+int tb_init(int device);
+int tb_device_cus(void);
+/* HIP-event timing of one kernel family (0 gemm, 1 lstm_fwd, 2 lstm_bwd, 3 loss, 4 optim,
+ * 5 gather, 6 band) on the stream it runs on; read after a device synchronise. */
+int tb_prof_enable(int kernel_id, int on);
+int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host);
+
+/* ---- LSTM layer (torch.nn.LSTM, one layer, batch_first, zero initial state) --------------------
+ * Reference call sites: source/utils/lstm_layer.py:31-33,44-46 (generator lstm0/1/2) and :75,83
+ * (discriminator); Gen-B twins source/models.py:44-46,64-66,101,111.
+ *   x (B,T,in)  w_ih (4H,in)  w_hh (4H,H)  b_ih,b_hh (4H)  gate order i,f,g,o
+ * forward : y (B,T,H).  `gates` (B,T,4H) receives the activated gates and `cstash` (B,T,H) the
+ *           cell states when train != 0 (the BPTT stash); with train == 0 `gates` is scratch and
+ *           cstash may be NULL.
+ * backward: dy (B,T,H) -> dx (B,T,in) [nullable], dw_ih, dw_hh, db_ih, db_hh [each nullable];
+ *           `gates` is consumed (overwritten with the pre-activation gradients).
+ * H must be one of 16,32,64,128,256,512 (tb_lstm_supported).  `err` is a device int[4]: err[0]
+ * becomes non-zero if an inter-workgroup wait timed out (results are then invalid). */
+int tb_lstm_supported(int H);
+size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward);
+int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                void* ws, size_t ws_bytes, int* err, void* stream);
+int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                float* db_hh, int B, int T, int in_dim, int H, void* ws, size_t ws_bytes, int* err,
+                void* stream);
+
+/* ---- Linear (+Tanh / +Sigmoid) -----------------------------------------------------------------
+ * y[M,N] = act(x[M,K].W[N,K]^T + b[N]); act 0 none, 1 tanh, 2 sigmoid.
+ * Reference: seq_layer / dim_layer / discriminator head, source/utils/lstm_layer.py:35-36,49-50,76,84-87.
+ * Backward takes dz = dy*act'(y) (tb_act_bwd) and produces dx = dz.W, dW = dz^T.x, db = colsum(dz). */
+int tb_linear_act_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int act,
+                      void* stream);
+size_t tb_linear_workspace_bytes(int M, int K, int N);
+int tb_linear_bwd(const float* dz, const float* x, const float* W, float* dx, float* dW, float* db, int M, int K,
+                  int N, void* ws, size_t ws_bytes, void* stream);
+int tb_act_bwd(const float* dy, const float* y, float* dz, long n, int act, void* stream);
+size_t tb_colsum_workspace_bytes(int cols);
+int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- losses (source/loss.py) ---------------------------------------------------------------------
+ * tb_loss_sums: one pass over whichever inputs are non-NULL into a device double[8]:
+ *   [0] sum (Dy-0.9)^2  [1] sum (DGx-0.1)^2  [2] sum Dy  [3] sum DGx  [4] sum SmoothL1(pred-true)
+ *   [5] sum (pred-true)^2.   GANLoss loss.py:34-51; l1loss/l2loss/_grad_penalty loss.py:127-141.
+ *   Under data parallelism the host all-reduces this vector before finish/grad (the gradient
+ *   penalty is a batch-global norm, loss.py:136-141).
+ * tb_loss_finish: mode 0 dis_loss (loss.py:114-119) out=[total,real,fake,0];
+ *                 mode 1 critic dis_loss (loss.py:107-112) out=[total,real,fake,gp];
+ *                 mode 2 gen_loss (loss.py:93-104) out=[total,adv,l1,l2,gp].
+ *   nD_*, nP, batch are GLOBAL element counts / batch size.  `running` (nullable float[8])
+ *   accumulates the logging sums of loss.py:99-102,117-118.
+ * grads: `upstream` is a device float (dL/dloss, nullable = 1). */
+size_t tb_loss_workspace_bytes(void);
+int tb_loss_sums(const float* Dy, long nDy, const float* DGx, long nDGx, const float* tru, const float* pred,
+                 long nP, double* sums, void* ws, size_t ws_bytes, void* stream);
+int tb_loss_finish(const double* sums, int mode, double nD_real, double nD_fake, double nP, double batch,
+                   float l1_w, float l2_w, float gp_w, float* out, float* running, void* stream);
+int tb_gan_loss_grad(const float* p, long n_local, double n_global, int target_is_real, int wgan,
+                     const float* upstream, float* dp, void* stream);
+int tb_recon_loss_grad(const float* tru, const float* pred, long n_local, double n_global, double batch,
+                       const double* sums, float l1_w, float l2_w, float gp_w, const float* upstream,
+                       float* dpred, int accumulate, void* stream);
+
+/* ---- optimizers over flat buffers (torch.optim defaults; schedule source/trainer.py:95-98,143-144) */
+int tb_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
+                 double eps, int step, void* stream);
+int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, double alpha, double eps, int fresh,
+                    void* stream);
+
+/* ---- data side ------------------------------------------------------------------------------------
+ * tb_window_gather: windows of the normalised series (source/dataset.py:199-214 + utils/dataset.py:17-23):
+ *   window w starts at row i = starts ? starts[w] : first + w*stride;
+ *   enc[w] = series[i-To:i, :] (To,E); dec[w] = series[i:i+Tf, target_cols] (Tf,V).
+ * tb_denormalize: source/dataset.py:229-242 (fp32 -> fp64 arithmetic -> fp32).
+ * tb_band_update: predicts(), source/trainer.py:266-287 = cleaner.py:158-179 = predictor.py:134-155.
+ *   pden (B,Tf,V) denormalised predictions; hist_in/hist_out (Tf-1,Tf,V) the predictions of the last
+ *   Tf-1 windows before/after this batch (distinct buffers; nhist = valid windows in hist_in);
+ *   med/sd/lower/upper (B+Tf-1,V) float64.
+ * tb_adjust_scan: adjust(); variant 0 trainer.py:238-257, 1 cleaner.py:130-149, 2 predictor.py:106-125.
+ *   seed (V) = the row before reals[0]; reals/preds/lower/upper (n,V) float64; masks (n,V) int32.
+ * tb_metrics: NME / NMAE / RMSE of source/metric.py:30-73 -> out[3] (+= running[3], nullable). */
+int tb_window_gather(const float* series, long series_len, int E, const long* starts, long first, long stride,
+                     int nwin, int To, int Tf, const int* target_cols, int V, float* enc, float* dec,
+                     void* stream);
+int tb_denormalize(const float* x, long n, int V, const double* dmin, const double* dmax, float* out, void* stream);
+int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
+                   double band_width, double* med, double* sd, double* lower, double* upper, void* stream);
+int tb_adjust_scan(int variant, const double* seed, const double* reals, const double* preds, const int* masks,
+                   const double* lower, const double* upper, int n, int V, double missing_gamma,
+                   double anomaly_gamma, double* target, void* stream);
+int tb_metrics(const double* tru, const double* pred, const int* mask, long n, double* out, double* running,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIMEBAND_HIP_H */

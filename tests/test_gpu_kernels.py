@@ -1,0 +1,371 @@
+"""GPU parity tests: every HIP entry point (through the C-ABI, via timeband_amd.ops) against the
+numpy oracle and the golden vectors captured from the reference.
+
+Tolerances (north_star): forward <= 1e-4 relative, gradients <= 1e-3; the fp32-MFMA kernels are
+exact-fp32 fma chains, so the observed gaps are ~1e-6 and most bounds below are tighter.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import timeband_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(autouse=True)
+def _check_kernel_errors():
+    yield
+    from timeband_amd import ops
+    ops.check_errors()
+
+
+def T(a, dev, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def sub(z, prefix):
+    prefix += "."
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def test_library_loaded_is_hip():
+    from timeband_amd import _lib
+    lib = _lib.load()
+    assert lib.tb_version() >= 1
+    assert os.path.basename(_lib.LIB_PATH) == "libtimeband_hip.so"
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N,act", [(64, 16, 64, 0), (100, 11, 7, 1), (333, 36, 256, 0), (130, 256, 1, 2),
+                                        (48 * 5, 48, 48, 0), (1000, 128, 32, 1), (17, 5, 3, 0)])
+def test_linear_fwd_bwd(dev, M, K, N, act):
+    from timeband_amd import ops
+    rng = np.random.default_rng(M + K + N)
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = rng.uniform(-0.3, 0.3, (N, K)).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, (N,)).astype(np.float32)
+    dy = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    z = x.astype(np.float64) @ W.T.astype(np.float64) + b
+    y_ref = {0: z, 1: np.tanh(z), 2: 1 / (1 + np.exp(-z))}[act]
+    xt, Wt, bt = T(x, dev).requires_grad_(), T(W, dev).requires_grad_(), T(b, dev).requires_grad_()
+    y = ops.linear_act(xt, Wt, bt, act)
+    assert rel(y.detach().cpu().numpy(), y_ref) < 1e-5
+    y.backward(T(dy, dev))
+    dz = dy * {0: 1.0, 1: 1 - y_ref ** 2, 2: y_ref * (1 - y_ref)}[act]
+    assert rel(xt.grad.cpu().numpy(), dz @ W.astype(np.float64)) < 1e-5
+    assert rel(Wt.grad.cpu().numpy(), dz.T @ x.astype(np.float64)) < 1e-5
+    assert rel(bt.grad.cpu().numpy(), dz.sum(0)) < 1e-5
+
+
+def test_gemm_splitk_large_k(dev):
+    """dW = dz^T.x with K = M = 40000 rows: exercises the split-K slabs + fixed-order reduce."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(5)
+    M, K, N = 40000, 24, 40
+    x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    W = rng.uniform(-0.3, 0.3, (N, K)).astype(np.float32)
+    dy = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    xt, Wt = T(x, dev), T(W, dev).requires_grad_()
+    y = ops.linear_act(xt, Wt, None, 0)
+    y.backward(T(dy, dev))
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    assert rel(Wt.grad.cpu().numpy(), ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+LSTM_CASES = [
+    # (B, T, in, H)
+    (5, 7, 3, 16), (16, 12, 11, 16), (33, 9, 16, 32), (8, 48, 32, 64), (70, 6, 7, 64),
+    (20, 10, 64, 128), (40, 12, 32, 256), (16, 5, 128, 256), (3, 4, 36, 512),
+]
+
+
+def lstm_params(rng, In, H):
+    k = 1.0 / np.sqrt(H)
+    return (rng.uniform(-k, k, (4 * H, In)).astype(np.float32), rng.uniform(-k, k, (4 * H, H)).astype(np.float32),
+            rng.uniform(-k, k, (4 * H,)).astype(np.float32), rng.uniform(-k, k, (4 * H,)).astype(np.float32))
+
+
+@pytest.mark.parametrize("B,Tn,In,H", LSTM_CASES)
+def test_lstm_layer_fwd_bwd(dev, B, Tn, In, H):
+    from timeband_amd import ops
+    rng = np.random.default_rng(B * 1000 + Tn * 10 + H)
+    w_ih, w_hh, b_ih, b_hh = lstm_params(rng, In, H)
+    x = rng.uniform(-1, 1, (B, Tn, In)).astype(np.float32)
+    dy = rng.uniform(-1, 1, (B, Tn, H)).astype(np.float32)
+    f64 = lambda a: a.astype(np.float64)
+    y_ref, cache = O.lstm_layer_fwd(f64(x), f64(w_ih), f64(w_hh), f64(b_ih), f64(b_hh))
+    dx_ref, dwi_ref, dwh_ref, dbi_ref, _ = O.lstm_layer_bwd(f64(dy), cache)
+    ts = [T(a, dev).requires_grad_() for a in (x, w_ih, w_hh, b_ih, b_hh)]
+    y = ops.lstm_layer(*ts)
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert rel(y.detach().cpu().numpy(), y_ref) < 2e-5, "forward"
+    # inference path (no stash) must give the same output
+    with torch.no_grad():
+        y2 = ops.lstm_layer(*[t.detach() for t in ts])
+    assert torch.equal(y2, y.detach())
+    y.backward(T(dy, dev))
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert rel(ts[0].grad.cpu().numpy(), dx_ref) < 1e-4, "dx"
+    assert rel(ts[1].grad.cpu().numpy(), dwi_ref) < 1e-4, "dw_ih"
+    assert rel(ts[2].grad.cpu().numpy(), dwh_ref) < 1e-4, "dw_hh"
+    assert rel(ts[3].grad.cpu().numpy(), dbi_ref) < 1e-4, "db_ih"
+    assert rel(ts[4].grad.cpu().numpy(), dbi_ref) < 1e-4, "db_hh"
+
+
+def test_lstm_many_clusters(dev):
+    """More batch tiles than one launch holds (B=700 at H=256 -> several M-tiles per cluster / launches)."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(77)
+    B, Tn, In, H = 700, 3, 8, 256
+    w_ih, w_hh, b_ih, b_hh = lstm_params(rng, In, H)
+    x = rng.uniform(-1, 1, (B, Tn, In)).astype(np.float32)
+    y_ref, _ = O.lstm_layer_fwd(x, w_ih, w_hh, b_ih, b_hh)
+    with torch.no_grad():
+        y = ops.lstm_layer(*[T(a, dev) for a in (x, w_ih, w_hh, b_ih, b_hh)])
+    assert rel(y.cpu().numpy(), y_ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+def build_nets(z, dev):
+    from timeband_amd.utils.lstm_layer import LSTMGenerator, LSTMDiscriminator
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    netD = LSTMDiscriminator(V, H, L, dev)
+    netG = LSTMGenerator(E, V, To, Tf, H, L, dev)
+    netD.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netD").items()})
+    netG.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netG").items()})
+    return netD.to(dev), netG.to(dev)
+
+
+def test_init_matches_reference_rng_order():
+    """Same seed -> same initial weights as the reference (D constructed before G, model.py:56-57)."""
+    from timeband_amd.utils.lstm_layer import LSTMGenerator, LSTMDiscriminator
+    from timeband_amd.utils.initiate import seeding
+    z = np.load(os.path.join(GOLDEN, "scenario_cfg1.npz"))
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    seeding(31)
+    netD = LSTMDiscriminator(V, H, L)
+    netG = LSTMGenerator(E, V, To, Tf, H, L)
+    for k, v in sub(z, "init.netD").items():
+        assert np.array_equal(netD.state_dict()[k].numpy(), v), k
+    for k, v in sub(z, "init.netG").items():
+        assert np.array_equal(netG.state_dict()[k].numpy(), v), k
+
+
+@pytest.mark.parametrize("name", ["cfg1", "uneven", "twolayer"])
+def test_forward_golden(dev, name):
+    z = np.load(os.path.join(GOLDEN, f"scenario_{name}.npz"))
+    netD, netG = build_nets(z, dev)
+    with torch.no_grad():
+        Gx = netG(T(z["x"], dev))
+        Dy = netD(T(z["y"], dev))
+        DGx = netD(Gx)
+    assert rel(Gx.cpu().numpy(), z["fwd.Gx"]) < 1e-4
+    assert rel(Dy.cpu().numpy(), z["fwd.Dy"]) < 1e-4
+    assert rel(DGx.cpu().numpy(), z["fwd.DGx"]) < 1e-4
+
+
+def grads_close(module, want, tol, what):
+    gmax = max(np.abs(v).max() for v in want.values())
+    for k, p in module.named_parameters():
+        err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
+        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
+
+
+def params_close(module, want, step, what):
+    nbad = ntot = 0
+    for k, v in module.state_dict().items():
+        d = np.abs(v.cpu().numpy().astype(np.float64) - want[k])
+        assert d.max() <= 2.1 * step, (what, k, d.max())
+        nbad += int((d > 0.05 * step).sum())
+        ntot += d.size
+    assert nbad / ntot < 1e-3, (what, nbad, ntot)
+
+
+@pytest.mark.parametrize("name", ["cfg1", "uneven", "twolayer"])
+def test_iteration_golden(dev, name):
+    """One Gen-A iteration (trainer.py:142-194) with the fused optimizers, against the reference."""
+    from timeband_amd.loss import TIMEBANDLoss
+    from timeband_amd.optim import FusedAdam, FusedRMSprop
+    z = np.load(os.path.join(GOLDEN, f"scenario_{name}.npz"))
+    lr = float(z["lr"])
+    netD, netG = build_nets(z, dev)
+    losses = TIMEBANDLoss(dict(l1_weight=50, l2_weight=50, gp_weight=50, device=dev))
+    adamD, adamG = FusedAdam(netD, lr), FusedAdam(netG, lr)
+
+    def iteration(tag, x, y, xc, yc, full):
+        optD = FusedRMSprop(netD, lr)
+        fake = netG(xc)
+        optD.zero_grad()
+        errD = losses.dis_loss(yc, fake, netD(yc), netD(fake), critic=True)
+        errD.backward()
+        assert rel(errD.item(), z[f"{tag}.critic.errD"]) < 1e-4
+        if full:
+            grads_close(netD, sub(z, f"{tag}.critic.grad.netD"), 1e-3, "critic grad D")
+        optD.step()
+        adamD.zero_grad()
+        adamG.zero_grad()
+        fake = netG(x)
+        errD = losses.dis_loss(y, fake, netD(y), netD(fake))
+        errD.backward()
+        assert rel(errD.item(), z[f"{tag}.dphase.errD"]) < 1e-4
+        if full:
+            grads_close(netD, sub(z, f"{tag}.dphase.grad.netD"), 1e-3, "dphase grad D")
+            grads_close(netG, sub(z, f"{tag}.dphase.grad.netG"), 1e-3, "dphase grad G")
+        adamD.step()
+        fake = netG(x)
+        errG = losses.gen_loss(y, fake, netD(fake))
+        errG.backward()
+        assert rel(errG.item(), z[f"{tag}.gphase.errG"]) < 1e-4
+        if full:
+            grads_close(netG, sub(z, f"{tag}.gphase.grad.netG"), 1e-3, "gphase grad G")
+        adamG.step()
+        assert rel(fake.detach().cpu().numpy(), z[f"{tag}.fake_y"]) < 1e-4
+
+    iteration("it0", T(z["x"], dev), T(z["y"], dev), T(z["xc"], dev), T(z["yc"], dev), True)
+    params_close(netD, sub(z, "it0.dphase.after.netD"), lr, "D after it0")
+    params_close(netG, sub(z, "it0.gphase.after.netG"), lr, "G after it0")
+    if name == "cfg1":
+        return
+    for it in (1, 2):
+        iteration(f"it{it}", *(T(z[f"it{it}.{k}"], dev) for k in ("x", "y", "xc", "yc")), False)
+    params_close(netD, sub(z, "it2.dphase.after.netD"), lr, "D after it2")
+    params_close(netG, sub(z, "it2.gphase.after.netG"), lr, "G after it2")
+
+
+# ---------------------------------------------------------------------------------------------
+def test_losses_vs_oracle(dev):
+    from timeband_amd import ops
+    rng = np.random.default_rng(3)
+    B, Tf, V = 9, 13, 5
+    tru = rng.uniform(-1, 1, (B, Tf, V)).astype(np.float32)
+    pred = (tru + rng.normal(0, 0.8, (B, Tf, V))).astype(np.float32)     # |d| crosses 1: both Huber branches
+    Dy = rng.uniform(0.05, 0.95, (B, Tf, 1)).astype(np.float32)
+    DGx = rng.uniform(0.05, 0.95, (B, Tf, 1)).astype(np.float32)
+    Lo = O.Losses(50, 40, 30)
+    # generator loss
+    pt, dt = T(pred, dev).requires_grad_(), T(DGx, dev).requires_grad_()
+    run = torch.zeros(8, device=dev)
+    total, out = ops.gen_loss(T(tru, dev), pt, dt, 50, 40, 30, run)
+    (total * 1.7).backward()
+    eG, dDGx, dpred = Lo.gen_loss(tru, pred, DGx)
+    assert rel(total.item(), eG) < 1e-5
+    assert rel(pt.grad.cpu().numpy(), 1.7 * dpred) < 1e-4
+    assert rel(dt.grad.cpu().numpy(), 1.7 * dDGx) < 1e-5
+    assert rel(run.cpu().numpy()[2:6], [Lo.err_Gen, Lo.errG_l1, Lo.errG_l2, Lo.errG_GP]) < 1e-5
+    # discriminator loss, both modes
+    for critic in (False, True):
+        yt, gt, pt = T(Dy, dev).requires_grad_(), T(DGx, dev).requires_grad_(), T(pred, dev).requires_grad_()
+        total, out = ops.dis_loss(yt, gt, T(tru, dev), pt, critic, 30.0, run)
+        total.backward()
+        e, dDy, dDG, dp = Lo.dis_loss(tru, pred, Dy, DGx, critic=critic)
+        assert rel(total.item(), e) < 1e-5
+        assert rel(yt.grad.cpu().numpy(), dDy) < 1e-5
+        assert rel(gt.grad.cpu().numpy(), dDG) < 1e-5
+        if critic:
+            assert rel(pt.grad.cpu().numpy(), dp) < 1e-4
+
+
+def test_optimizers_vs_oracle(dev):
+    from timeband_amd import ops
+    rng = np.random.default_rng(4)
+    n = 10007
+    p0 = rng.normal(0, 0.1, n).astype(np.float32)
+    P = {"w": p0.copy()}
+    ad = O.Adam(2e-4)
+    pt = T(p0, dev)
+    m, v = torch.zeros_like(pt), torch.zeros_like(pt)
+    for step in range(1, 4):
+        g = rng.normal(0, 1e-3, n).astype(np.float32)
+        ad.step(P, {"w": g})
+        ops.adam_step(pt, T(g, dev), m, v, 2e-4, step)
+        assert np.abs(pt.cpu().numpy() - P["w"]).max() < 6e-8   # <= 2 ulp of |p| ~ 0.4
+    P = {"w": p0.copy()}
+    rm = O.RMSprop(2e-4)
+    pt = T(p0, dev)
+    sq = torch.empty_like(pt)
+    for step in range(2):
+        g = rng.normal(0, 1e-3, n).astype(np.float32)
+        rm.step(P, {"w": g})
+        ops.rmsprop_step(pt, T(g, dev), sq, 2e-4, fresh=(step == 0))
+        assert np.abs(pt.cpu().numpy() - P["w"]).max() < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------
+def test_window_gather(dev):
+    from timeband_amd import ops
+    rng = np.random.default_rng(9)
+    n, E, To, Tf = 300, 11, 24, 12
+    series = rng.uniform(-1, 1, (n, E)).astype(np.float32)
+    tcols = np.array([4, 6, 10], np.int32)
+    enc_ref, dec_ref = O.windowing(series, tcols, To, Tf)
+    st = T(series, dev)
+    tc = torch.tensor(tcols, dtype=torch.int32, device=dev)
+    enc, dec = ops.window_gather(st, tc, To + 5, 40, To, Tf)
+    assert np.array_equal(enc.cpu().numpy(), enc_ref[5:45]) and np.array_equal(dec.cpu().numpy(), dec_ref[5:45])
+    starts = torch.tensor([To, To + 100, n - Tf], dtype=torch.int64, device=dev)
+    enc, dec = ops.window_gather(st, tc, 0, 3, To, Tf, starts=starts)
+    assert np.array_equal(enc.cpu().numpy(), enc_ref[[0, 100, n - Tf - To]])
+    assert np.array_equal(dec.cpu().numpy(), dec_ref[[0, 100, n - Tf - To]])
+    with pytest.raises(RuntimeError):
+        ops.window_gather(st, tc, n - Tf + 1, 1, To, Tf)     # last window would leave the series
+
+
+def test_band_adjust_metric_golden(dev):
+    """tb_band_update / tb_adjust_scan / tb_metrics against the reference's own outputs."""
+    from timeband_amd import ops
+    z = np.load(os.path.join(GOLDEN, "band_adjust.npz"))
+    for tag, Tf, V, w, n, cls in (("band", 5, 3, 1.5, 4, ".trainer"), ("band2", 2, 2, 1.0, 3, ""),
+                                  ("band6", 6, 2, 2.0, 4, "")):
+        hist = [torch.zeros(Tf - 1, Tf, V, device=dev), torch.zeros(Tf - 1, Tf, V, device=dev)]
+        nhist = 0
+        for i in range(n):
+            pred = T(z[f"{tag}.pred{i}"], dev)
+            med, lo, up = ops.band_update(pred, hist[i & 1], nhist, hist[(i + 1) & 1], w)
+            nhist = min(Tf - 1, nhist + pred.shape[0])
+            assert np.array_equal(med.cpu().numpy(), z[f"{tag}{cls}.preds{i}"]), (tag, i)
+            np.testing.assert_allclose(lo.cpu().numpy(), z[f"{tag}{cls}.lower{i}"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(up.cpu().numpy(), z[f"{tag}{cls}.upper{i}"], rtol=1e-12, atol=1e-12)
+    for variant in ("trainer", "cleaner", "predictor"):
+        out0 = z["adj.output"]
+        tgt = ops.adjust_scan(variant, T(out0[0], dev, torch.float64), T(out0[1:], dev, torch.float64),
+                              T(z["adj.preds"], dev, torch.float64), T(z["adj.masks"], dev, torch.int32),
+                              T(z["adj.lower"], dev, torch.float64), T(z["adj.upper"], dev, torch.float64),
+                              float(z["adj.a"]), float(z["adj.b"]))
+        np.testing.assert_allclose(tgt.cpu().numpy(), z[f"adj.{variant}.target"], rtol=1e-14, atol=0)
+    zm = np.load(os.path.join(GOLDEN, "metric.npz"))
+    run = torch.zeros(3, dtype=torch.float64, device=dev)
+    for i in range(3):
+        out = ops.metrics(T(zm[f"true{i}"], dev, torch.float64), T(zm[f"pred{i}"], dev, torch.float64),
+                          T(zm[f"mask{i}"], dev, torch.int32), run)
+        np.testing.assert_allclose(out.cpu().numpy(), [zm[f"nme{i}"], zm[f"nmae{i}"], zm[f"rmse{i}"]], rtol=1e-12)
+
+
+def test_denormalize_bit_exact(dev):
+    from timeband_amd import ops
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, (7, 5, 4)).astype(np.float32)
+    dmin = rng.normal(0, 3, 4)
+    dmax = dmin + rng.uniform(0.5, 9, 4)
+    got = ops.denormalize(T(x, dev), T(dmin, dev, torch.float64), T(dmax, dev, torch.float64))
+    assert np.array_equal(got.cpu().numpy(), O.denormalize(x, dmin, dmax))

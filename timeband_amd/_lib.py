@@ -1,0 +1,88 @@
+"""ctypes binding of libtimeband_hip.so (C-ABI: include/timeband_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtimeband_hip.so")
+
+_lib = None
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_long
+D = C.c_double
+F = C.c_float
+Z = C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/timeband_hip.h declares
+SIGNATURES = {
+    "tb_version": (I, []),
+    "tb_last_error": (C.c_char_p, []),
+    "tb_init": (I, [I]),
+    "tb_device_cus": (I, []),
+    "tb_prof_enable": (I, [I, I]),
+    "tb_prof_read": (I, [I, C.POINTER(I), C.POINTER(D)]),
+    "tb_lstm_supported": (I, [I]),
+    "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
+    "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, Z, P, P]),
+    "tb_linear_act_fwd": (I, [P, P, P, P, I, I, I, I, P]),
+    "tb_linear_workspace_bytes": (Z, [I, I, I]),
+    "tb_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
+    "tb_act_bwd": (I, [P, P, P, L, I, P]),
+    "tb_colsum_workspace_bytes": (Z, [I]),
+    "tb_colsum": (I, [P, L, I, P, P, Z, P]),
+    "tb_loss_workspace_bytes": (Z, []),
+    "tb_loss_sums": (I, [P, L, P, L, P, P, L, P, P, Z, P]),
+    "tb_loss_finish": (I, [P, I, D, D, D, D, F, F, F, P, P, P]),
+    "tb_gan_loss_grad": (I, [P, L, D, I, I, P, P, P]),
+    "tb_recon_loss_grad": (I, [P, P, L, D, D, P, F, F, F, P, P, I, P]),
+    "tb_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),
+    "tb_rmsprop_step": (I, [P, P, P, L, D, D, D, I, P]),
+    "tb_window_gather": (I, [P, L, I, P, L, L, I, I, I, P, I, P, P, P]),
+    "tb_denormalize": (I, [P, L, I, P, P, P, P]),
+    "tb_band_update": (I, [P, I, I, I, P, I, P, D, P, P, P, P, P]),
+    "tb_adjust_scan": (I, [I, P, P, P, P, P, P, I, I, D, D, P, P]),
+    "tb_metrics": (I, [P, P, P, L, P, P, P]),
+}
+
+K_GEMM, K_LSTM_FWD, K_LSTM_BWD, K_LOSS, K_OPTIM, K_GATHER, K_BAND = range(7)
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m timeband_amd.build` "
+            "(there is no CPU/PyTorch fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().tb_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on a non-zero return."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

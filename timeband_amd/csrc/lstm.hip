@@ -1,0 +1,684 @@
+// K2 / K3: persistent LSTM recurrent forward and fused backward-through-time for gfx950.
+//
+// Replaces aten::lstm / its autograd (cuDNN or oneDNN under torch) as called by the reference
+// at source/utils/lstm_layer.py:31-33,44-46 (generator lstm0/1/2) and :75,83 (discriminator):
+// torch.nn.LSTM semantics, gate order i,f,g,o, two biases, batch_first, zero initial state.
+//
+// Decomposition (one layer):
+//   forward : P = x.W_ih^T + b_ih + b_hh        (K1 GEMM, all timesteps at once)
+//             persistent recurrent kernel over t (this file): a = P_t + h_{t-1}.W_hh^T,
+//             fused sigmoid/tanh, c/h update; activated gates overwrite P in place (BPTT stash)
+//   backward: persistent BPTT kernel over t (this file): dgates_t overwrite the stash in place,
+//             dh_{t-1} = dgates_t.W_hh; bias grads accumulated in registers
+//             then K1 GEMMs: dx = dG.W_ih, dW_ih = dG^T.x, dW_hh = dG^T.h_prev
+//
+// Persistent kernel layout.  The batch is cut into tiles of 16*MT rows; a CLUSTER of NCL = H/US
+// workgroups (one per CU, all co-resident: grid <= #CUs) owns one tile.  Member j owns hidden
+// units [j*US, (j+1)*US): in forward the 4*US rows of W_hh that produce its gates, held in
+// VGPRs for the whole sequence as MFMA B-operand fragments (W_hh never leaves the register file
+// between timesteps); c stays in registers too.  Each timestep every member needs the whole
+// h_{t-1} tile: members write their h slice to y[b,t,:] with write-through (sc1) stores, raise a
+// per-member step counter, poll the other members' counters (bounded spin) and read the other
+// slices with L1-bypassing (sc1) loads -- the Guideline-16 protocol of cdna_hip_programming.md.
+// In backward the same W_hh rows are the B operand of dh_{t-1} = dgates_t.W_hh; the per-member
+// partial sums over gate rows are exchanged reduce-scatter style through a double-buffered slab.
+// NCL == 1 (H <= 64) needs no global exchange at all.
+#include "common.h"
+
+int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                   long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
+                   float* ws, size_t ws_bytes, hipStream_t stream);
+
+namespace {
+
+struct FwdArgs {
+  float* P;            // [B][T][4H] in: pre-activations from the projection; out: activated gates
+  const float* Whh;    // [4H][H]
+  float* y;            // [B][T][H]
+  float* cst;          // [B][T][H] cell stash (train) or nullptr
+  unsigned* flags;     // [nclusters][NCL] step counters, zeroed before launch
+  int* err;            // [4] sticky error words
+  int B, T;
+  int b_begin;         // first batch row of this launch
+  int nclusters;
+  int train;
+  unsigned long long timeout_ticks;
+};
+
+__device__ __forceinline__ int hl_off(int row, int k) {
+  // LDS image of a [16][K] tile laid out so that one ds_read_b128 per lane yields the MFMA A
+  // operand of 4 consecutive k-steps: float offset of element (row, k).
+  return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + row) << 2) + (k & 3);
+}
+
+// cluster/member decode: keep the members of a cluster on blocks with equal (blockIdx % 8), i.e.
+// on one XCD under the observed round-robin placement (speed only; correctness never depends on it)
+__device__ __forceinline__ void cluster_decode(int ncl, int NCL, int& cl, int& j) {
+  const int G = gridDim.x, b = blockIdx.x;
+  if ((G & 7) == 0 && ((G >> 3) % NCL) == 0) {
+    const int x = b & 7, slot = b >> 3, per = (G >> 3) / NCL;
+    cl = x * per + slot / NCL;
+    j = slot % NCL;
+  } else {
+    cl = b / NCL;
+    j = b % NCL;
+  }
+  (void)ncl;
+}
+
+// Wait until every other member's counter reaches `target`.  Returns false on timeout.
+__device__ __forceinline__ bool wait_members(const unsigned* flags, int NCL, int j, unsigned target,
+                                             unsigned long long timeout, int* err, int* s_dead) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    bool ok = true;
+    if (lane < NCL && lane != j) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned it = 0;
+      while (tb_load_agent_u32(flags + lane) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 1023u) == 0 && wall_clock64() - t0 > timeout) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    if (!ok) {
+      atomicExch(err, 1);
+      *s_dead = 1;
+    }
+  }
+  __syncthreads();
+  return *s_dead == 0;
+}
+
+template <int H, int US, int KS, int MT>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
+  constexpr int NUG = US / 16;          // 16-unit groups per member
+  constexpr int NCL = H / US;           // members per cluster
+  constexpr int KPER = H / KS;          // k range per wave
+  constexpr int KG = KPER / 16;         // 16-wide k groups per wave
+  constexpr int NACT = NUG * KS;        // waves doing MFMA work
+  constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
+  static_assert(NACT <= 4 && KPER % 16 == 0 && H % US == 0, "bad config");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hL = smem;                                    // [MT][H/16][64][4]
+  float* red = smem + MT * H * 16;                     // [MT][NUG][KS-1][4][64][4]
+  int* s_dead = reinterpret_cast<int*>(smem + MT * H * 16 + RED);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  int cl, j;
+  cluster_decode(a.nclusters, NCL, cl, j);
+  const bool active = wave < NACT;
+  const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
+  const bool owner = active && kp == 0;
+  const int u = j * US + ug * 16 + col;                // hidden unit of this lane
+  const int b0 = a.b_begin + cl * 16 * MT;
+  const int T = a.T;
+  const long rowP = (long)T * 4 * H, rowY = (long)T * H;
+  unsigned* flags = a.flags + cl * NCL;
+  if (tid == 0) *s_dead = 0;
+
+  // W_hh fragments: B[k][n] = W_hh[g*H + u][k]; MFMA step (kg,i) uses k = kp*KPER + kg*16 + q*4 + i
+  float w[4][KG * 4];
+  if (active) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + u) * H + kp * KPER + kg * 16 + q * 4);
+        w[g][kg * 4 + 0] = v[0]; w[g][kg * 4 + 1] = v[1]; w[g][kg * 4 + 2] = v[2]; w[g][kg * 4 + 3] = v[3];
+      }
+  }
+  float c[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[mt][r] = 0.f;
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    // (A) owners: pre-activations of this step (independent of the recurrence -> issued first)
+    float pre[MT][4][4];
+    if (owner) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = b0 + mt * 16 + q * 4 + r;
+          const bool ok = b < a.B;
+          const float* p = a.P + (long)(ok ? b : 0) * rowP + (long)t * 4 * H + u;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pre[mt][g][r] = ok ? p[g * H] : 0.f;
+        }
+    }
+    // (B) h_{t-1}.W_hh^T on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[mt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t > 0 && active) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(hL + ((mt * (H / 16) + kp * KG + kg) * 64 + lane) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], w[g][kg * 4 + i], acc[mt][g], 0, 0, 0);
+        }
+        if (KS > 1 && kp > 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + (kp - 1)) * 4 + g) * 64 + lane) * 4) =
+                acc[mt][g];
+        }
+      }
+    }
+    __syncthreads();   // all reads of hL done; k-split partials visible
+    // (C) owners: gate math, state update, stores
+    if (owner) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          z[g] = acc[mt][g];
+          if (KS > 1 && t > 0) {
+#pragma unroll
+            for (int p2 = 0; p2 < KS - 1; ++p2) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(
+                  red + ((((mt * NUG + ug) * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
+              z[g] += o;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = q * 4 + r;
+          const int b = b0 + mt * 16 + row;
+          const float ig = tb_sigmoid(z[0][r] + pre[mt][0][r]);
+          const float fg = tb_sigmoid(z[1][r] + pre[mt][1][r]);
+          const float gg = tanhf(z[2][r] + pre[mt][2][r]);
+          const float og = tb_sigmoid(z[3][r] + pre[mt][3][r]);
+          const float cn = fg * c[mt][r] + ig * gg;
+          c[mt][r] = cn;
+          const float hn = og * tanhf(cn);
+          hL[mt * H * 16 + hl_off(row, u)] = hn;
+          if (b < a.B) {
+            float* yp = a.y + (long)b * rowY + (long)t * H + u;
+            if (NCL > 1) tb_store_agent(yp, hn);
+            else *yp = hn;
+            if (a.train) {
+              float* p = a.P + (long)b * rowP + (long)t * 4 * H + u;
+              p[0] = ig; p[H] = fg; p[2 * H] = gg; p[3 * H] = og;
+              a.cst[(long)b * rowY + (long)t * H + u] = cn;
+            }
+          }
+        }
+      }
+    }
+    if (NCL > 1) {
+      if (t + 1 < T) {
+        // (D) publish this member's h slice, then pull the other members' slices
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
+        if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
+        constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
+        for (int e = tid; e < NV; e += 256) {
+          const int row = e & 15;
+          const int c4 = (e >> 4) % (H / 4);
+          const int mt = e / (16 * (H / 4));
+          const int k = c4 * 4;
+          if (k >= j * US && k < (j + 1) * US) continue;   // own slice already in LDS
+          const int b = b0 + mt * 16 + row;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (b < a.B) {
+            const float* src = a.y + (long)b * rowY + (long)t * H + k;
+            v[0] = tb_load_agent(src); v[1] = tb_load_agent(src + 1);
+            v[2] = tb_load_agent(src + 2); v[3] = tb_load_agent(src + 3);
+          }
+          *reinterpret_cast<f32x4*>(hL + mt * H * 16 + hl_off(row, k)) = v;
+        }
+      }
+    }
+    __syncthreads();   // hL complete for step t+1
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+struct BwdArgs {
+  float* G;            // [B][T][4H] in: activated gates; out: dgates (wrt pre-activations)
+  const float* cst;    // [B][T][H]
+  const float* dy;     // [B][T][H]
+  const float* Whh;    // [4H][H]
+  float* X;            // [nclusters][2][NCL][MT*16][H] exchange slabs (NCL > 1)
+  float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
+  unsigned* flags;
+  int* err;
+  int B, T;
+  int b_begin;
+  int cl_begin;        // index of this launch's first cluster in dbpart
+  int nclusters;
+  unsigned long long timeout_ticks;
+};
+
+template <int H, int US, int MT>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
+  constexpr int NCL = H / US;
+  constexpr int KD = 4 * US;                       // k dimension = this member's gate rows
+  constexpr int KGD = KD / 16;
+  constexpr int NTW = H >= 64 ? H / 64 : 1;        // 16-col output tiles per wave
+  constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
+  constexpr int NI = MT * 16 * US / 256;           // (row,unit) items per thread
+  constexpr int LDH = H + 4;                       // dhL row stride (floats)
+  static_assert(NI >= 1 && (256 % US) == 0, "bad config");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dgL = smem;                               // [MT][KD/16][64][4]
+  float* dhL = smem + MT * KD * 16;                // [MT][16][LDH] this member's partial dh_{t-1}
+  float* dbL = dhL + MT * 16 * LDH;                // [256][4] bias-grad reduction
+  int* s_dead = reinterpret_cast<int*>(dbL + 1024);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  int cl, j;
+  cluster_decode(a.nclusters, NCL, cl, j);
+  const int b0 = a.b_begin + cl * 16 * MT;
+  const int T = a.T;
+  const long rowG = (long)T * 4 * H, rowY = (long)T * H;
+  unsigned* flags = a.flags + cl * NCL;
+  float* Xc = a.X + (size_t)cl * 2 * NCL * MT * 16 * H;
+  if (tid == 0) *s_dead = 0;
+
+  // W_hh fragments: B[k][n] = W_hh[grow(k)][n], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
+  float wb[NTW][KGD * 4];
+  const bool mactive = wave < NAW;
+  if (mactive) {
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int s = 0; s < KGD * 4; ++s) {
+        const int k = (s >> 2) * 16 + q * 4 + (s & 3);
+        const int grow = (k / US) * H + j * US + (k % US);
+        wb[nt][s] = a.Whh[(long)grow * H + (wave * NTW + nt) * 16 + col];
+      }
+  }
+  // elementwise items: e = tid + 256*n -> ul = e % US (constant per thread), row, mt
+  const int ul = tid % US;
+  const int uabs = j * US + ul;
+  float dc[NI], dhrec[NI], dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < NI; ++n) { dc[n] = 0.f; dhrec[n] = 0.f; }
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    // (A) gate gradients for this member's units
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int e = tid + 256 * n;
+      const int row = (e / US) & 15, mt = e / (16 * US);
+      const int b = b0 + mt * 16 + row;
+      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
+      if (b < a.B) {
+        float* gp = a.G + (long)b * rowG + (long)t * 4 * H + uabs;
+        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+        const float ct = a.cst[(long)b * rowY + (long)t * H + uabs];
+        const float cprev = t > 0 ? a.cst[(long)b * rowY + (long)(t - 1) * H + uabs] : 0.f;
+        const float dh = a.dy[(long)b * rowY + (long)t * H + uabs] + dhrec[n];
+        const float tc = tanhf(ct);
+        const float dcn = dc[n] + dh * og * (1.f - tc * tc);
+        dob = dh * tc * og * (1.f - og);
+        di = dcn * gg * ig * (1.f - ig);
+        dg = dcn * ig * (1.f - gg * gg);
+        df = dcn * cprev * fg * (1.f - fg);
+        dc[n] = dcn * fg;
+        gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dob;
+        dbacc[0] += di; dbacc[1] += df; dbacc[2] += dg; dbacc[3] += dob;
+      }
+      float* dl = dgL + mt * KD * 16;
+      dl[hl_off(row, ul)] = di;
+      dl[hl_off(row, US + ul)] = df;
+      dl[hl_off(row, 2 * US + ul)] = dg;
+      dl[hl_off(row, 3 * US + ul)] = dob;
+    }
+    if (t == 0) break;     // dh_{-1} is never used
+    __syncthreads();
+    // (B) partial dh_{t-1} = dgates_t . W_hh[rows of this member]
+    const int par = t & 1;
+    if (mactive) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 acc[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kg = 0; kg < KGD; ++kg) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wb[nt][kg * 4 + i], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int ncol = (wave * NTW + nt) * 16 + col;
+          const bool own = (ncol / US) == j;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            if (NCL == 1 || own) dhL[(mt * 16 + row) * LDH + ncol] = acc[nt][r];
+            else tb_store_agent(Xc + ((size_t)(par * NCL + j) * MT * 16 + mt * 16 + row) * H + ncol, acc[nt][r]);
+          }
+        }
+      }
+    }
+    if (NCL > 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned step = (unsigned)(T - t);      // 1, 2, ... monotonic
+      if (tid == 0) tb_store_agent_u32(flags + j, step);
+      if (!wait_members(flags, NCL, j, step, a.timeout_ticks, a.err, s_dead)) break;
+    } else {
+      __syncthreads();
+    }
+    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int e = tid + 256 * n;
+      const int row = (e / US) & 15, mt = e / (16 * US);
+      float s = dhL[(mt * 16 + row) * LDH + uabs];
+      if (NCL > 1) {
+        for (int m = 0; m < NCL; ++m) {
+          if (m == j) continue;
+          s += tb_load_agent(Xc + ((size_t)(par * NCL + m) * MT * 16 + mt * 16 + row) * H + uabs);
+        }
+      }
+      dhrec[n] = s;
+    }
+    __syncthreads();   // dhL / dgL free for the next step
+  }
+  // bias grads of this cluster: reduce the threads that share a unit, one partial row per cluster
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dbL[tid * 4 + g] = dbacc[g];
+  __syncthreads();
+  if (tid < US) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = tid; k < 256; k += US)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s[g] += dbL[k * 4 + g];
+    float* out = a.dbpart + (size_t)(a.cl_begin + cl) * 4 * H;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g * H + j * US + tid] = s[g];
+  }
+}
+
+__global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* db_ih, float* db_hh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+  if (db_ih) db_ih[i] = s;
+  if (db_hh) db_hh[i] = s;
+}
+
+__global__ void bias_sum_kernel(const float* b1, const float* b2, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = b1[i] + b2[i];
+}
+
+// ---- launch planning ---------------------------------------------------------------------
+struct Plan {
+  int H, US, KS, MT;
+  int NCL;
+  int rows_per_cluster;
+  int clusters_per_launch;
+  size_t lds_fwd, lds_bwd;
+};
+
+bool make_plan(int H, int B, Plan& p) {
+  int US, KS;
+  switch (H) {
+    case 16: US = 16; KS = 1; break;
+    case 32: US = 32; KS = 2; break;
+    case 64: US = 64; KS = 1; break;
+    case 128: US = 32; KS = 2; break;
+    case 256: US = 32; KS = 2; break;
+    case 512: US = 16; KS = 4; break;
+    default: return false;
+  }
+  p.H = H; p.US = US; p.KS = KS; p.NCL = H / US;
+  const int cus = tb_num_cus();
+  const int max_clusters = cus / p.NCL > 0 ? cus / p.NCL : 1;
+  int MT = 1;
+  const int mt_cap = (H >= 512) ? 1 : (H >= 256 ? 2 : 4);
+  while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters) MT *= 2;
+  p.MT = MT;
+  p.rows_per_cluster = 16 * MT;
+  p.clusters_per_launch = max_clusters;
+  const int NUG = US / 16;
+  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
+  p.lds_bwd = ((size_t)MT * 4 * US * 16 + (size_t)MT * 16 * (H + 4) + 1024) * 4 + 16;
+  return true;
+}
+
+template <int H, int US, int KS, int MT>
+int launch_fwd_t(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, US, KS, MT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, US, KS, MT>), dim3(grid), dim3(256), lds, s, a);
+  TB_LAUNCH_CHECK("lstm_fwd_kernel");
+  return TB_OK;
+}
+
+template <int H, int US, int MT>
+int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, US, MT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, US, MT>), dim3(grid), dim3(256), lds, s, a);
+  TB_LAUNCH_CHECK("lstm_bwd_kernel");
+  return TB_OK;
+}
+
+#define FWD_CASE(h, us, ks, mt) \
+  if (p.H == h && p.MT == mt) return launch_fwd_t<h, us, ks, mt>(a, grid, p.lds_fwd, s)
+#define BWD_CASE(h, us, mt) \
+  if (p.H == h && p.MT == mt) return launch_bwd_t<h, us, mt>(a, grid, p.lds_bwd, s)
+
+int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
+  FWD_CASE(16, 16, 1, 1); FWD_CASE(16, 16, 1, 2); FWD_CASE(16, 16, 1, 4);
+  FWD_CASE(32, 32, 2, 1); FWD_CASE(32, 32, 2, 2); FWD_CASE(32, 32, 2, 4);
+  FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2); FWD_CASE(64, 64, 1, 4);
+  FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
+  FWD_CASE(256, 32, 2, 1); FWD_CASE(256, 32, 2, 2);
+  FWD_CASE(512, 16, 4, 1);
+  return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
+}
+
+int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
+  BWD_CASE(16, 16, 1); BWD_CASE(16, 16, 2); BWD_CASE(16, 16, 4);
+  BWD_CASE(32, 32, 1); BWD_CASE(32, 32, 2); BWD_CASE(32, 32, 4);
+  BWD_CASE(64, 64, 1); BWD_CASE(64, 64, 2); BWD_CASE(64, 64, 4);
+  BWD_CASE(128, 32, 1); BWD_CASE(128, 32, 2); BWD_CASE(128, 32, 4);
+  BWD_CASE(256, 32, 1); BWD_CASE(256, 32, 2);
+  BWD_CASE(512, 16, 1);
+  return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: no kernel for H=%d MT=%d", p.H, p.MT);
+}
+
+constexpr unsigned long long kTimeoutTicks = 200000000ull;   // 2 s of the 100 MHz realtime counter
+
+// workspace carve: [flags | bias sum | dbpart | X | gemm split-k slabs]
+struct Carve {
+  unsigned* flags; size_t flags_bytes;
+  float* bsum;
+  float* dbpart;
+  float* X;
+  float* gemm_ws; size_t gemm_ws_bytes;
+};
+
+size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
+  const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
+  size_t off = 0;
+  const size_t flags_bytes = tb_align_up((size_t)ncl_total * p.NCL * sizeof(unsigned), 256);
+  const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
+  const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
+  const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
+  const size_t x_bytes = (bwd && p.NCL > 1)
+                             ? tb_align_up((size_t)ncl_launch * 2 * p.NCL * p.rows_per_cluster * H * sizeof(float), 256)
+                             : 0;
+  const int widest = in_dim > H ? in_dim : H;
+  const size_t gemm_bytes = bwd ? tb_align_up((size_t)64 * 4 * H * widest * sizeof(float), 256) : 0;
+  if (c) {
+    c->flags = reinterpret_cast<unsigned*>(base + off); c->flags_bytes = flags_bytes;
+  }
+  off += flags_bytes;
+  if (c) c->bsum = reinterpret_cast<float*>(base + off);
+  off += bsum_bytes;
+  if (c) c->dbpart = reinterpret_cast<float*>(base + off);
+  off += dbpart_bytes;
+  if (c) c->X = reinterpret_cast<float*>(base + off);
+  off += x_bytes;
+  if (c) {
+    c->gemm_ws = reinterpret_cast<float*>(base + off);
+    c->gemm_ws_bytes = total > off ? total - off : 0;
+  }
+  off += gemm_bytes;
+  return off;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
+  (void)T;
+  Plan p;
+  if (!make_plan(H, B, p)) return 0;
+  return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
+}
+
+int tb_lstm_supported(int H) {
+  Plan p;
+  return make_plan(H, 16, p) ? 1 : 0;
+}
+
+int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                void* ws, size_t ws_bytes, int* err, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B <= 0 || T <= 0) return TB_OK;
+  if (!x || !w_ih || !w_hh || !y || !gates || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
+  if (train && !cstash) return tb_set_error(TB_ERR_ARG, "lstm_fwd: train needs a cell stash");
+  Plan p;
+  if (!make_plan(H, B, p))
+    return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d not supported (16,32,64,128,256,512)", H);
+  Carve c;
+  const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
+  if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
+  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
+  // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash
+  const float* bias = nullptr;
+  if (b_ih && b_hh) {
+    hipLaunchKernelGGL(bias_sum_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, b_ih, b_hh, c.bsum, 4 * H);
+    TB_LAUNCH_CHECK("bias_sum_kernel");
+    bias = c.bsum;
+  }
+  int rc = tb_gemm_launch(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, bias, B * T, 4 * H, in_dim, 0, 0, 1,
+                          nullptr, 0, s);
+  if (rc) return rc;
+  const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
+  tb_prof_begin(TB_K_LSTM_FWD, s);
+  for (int c0 = 0; c0 < ncl_total; c0 += p.clusters_per_launch) {
+    const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
+    FwdArgs a;
+    a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
+    a.flags = c.flags + (size_t)c0 * p.NCL;
+    a.err = err;
+    a.B = B; a.T = T;
+    a.b_begin = c0 * p.rows_per_cluster;
+    a.nclusters = ncl;
+    a.train = train;
+    a.timeout_ticks = kTimeoutTicks;
+    rc = launch_fwd(p, a, ncl * p.NCL, s);
+    if (rc) return rc;
+  }
+  tb_prof_end(TB_K_LSTM_FWD, s);
+  return TB_OK;
+}
+
+int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                float* db_hh, int B, int T, int in_dim, int H, void* ws, size_t ws_bytes, int* err,
+                void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B <= 0 || T <= 0) return TB_OK;
+  if (!dy || !x || !w_ih || !w_hh || !y || !gates || !cstash || !ws || !err)
+    return tb_set_error(TB_ERR_ARG, "lstm_bwd: null pointer");
+  Plan p;
+  if (!make_plan(H, B, p))
+    return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d not supported (16,32,64,128,256,512)", H);
+  Carve c;
+  const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c);
+  if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
+  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
+  const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
+  int rc;
+  tb_prof_begin(TB_K_LSTM_BWD, s);
+  for (int c0 = 0; c0 < ncl_total; c0 += p.clusters_per_launch) {
+    const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
+    BwdArgs a;
+    a.G = gates; a.cst = cstash; a.dy = dy; a.Whh = w_hh;
+    a.X = c.X;
+    a.dbpart = c.dbpart;
+    a.flags = c.flags + (size_t)c0 * p.NCL;
+    a.err = err;
+    a.B = B; a.T = T;
+    a.b_begin = c0 * p.rows_per_cluster;
+    a.cl_begin = c0;
+    a.nclusters = ncl;
+    a.timeout_ticks = kTimeoutTicks;
+    rc = launch_bwd(p, a, ncl * p.NCL, s);
+    if (rc) return rc;
+  }
+  tb_prof_end(TB_K_LSTM_BWD, s);
+  if (db_ih || db_hh) {
+    hipLaunchKernelGGL(db_reduce_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, c.dbpart, ncl_total, 4 * H,
+                       db_ih, db_hh);
+    TB_LAUNCH_CHECK("db_reduce_kernel");
+  }
+  const int M = B * T;
+  if (dx) {   // dx = dG . W_ih            [M,4H].[4H,in]
+    rc = tb_gemm_launch(gates, 4L * H, 0, w_ih, in_dim, 1, dx, in_dim, nullptr, M, in_dim, 4 * H, 0, 0, 1,
+                        c.gemm_ws, c.gemm_ws_bytes, s);
+    if (rc) return rc;
+  }
+  if (dw_ih) {  // dW_ih = dG^T . x        [4H,M].[M,in]
+    rc = tb_gemm_launch(gates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, nullptr, 4 * H, in_dim, M, 0, 0, 1,
+                        c.gemm_ws, c.gemm_ws_bytes, s);
+    if (rc) return rc;
+  }
+  if (dw_hh) {  // dW_hh = dG^T . h_prev,  h_prev[b,t] = y[b,t-1], 0 at t = 0
+    rc = tb_gemm_launch(gates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, c.gemm_ws,
+                        c.gemm_ws_bytes, s);
+    if (rc) return rc;
+  }
+  return TB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,376 @@
+"""torch.autograd bindings over the C-ABI (include/timeband_hip.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream, autograd
+bookkeeping and torch.distributed.  Every arithmetic op of the hot path is a HIP kernel of
+libtimeband_hip.so; there is no eager/CPU fallback -- a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("timeband_amd ops run on the GPU only (got a CPU tensor); "
+                               "there is no CPU fallback in the product path")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Runtime:
+    """Per-device scratch: one growable workspace, the sticky error words, lazily initialised."""
+    _by_device = {}
+
+    def __init__(self, device):
+        self.device = device
+        with torch.cuda.device(device):
+            _lib.call("tb_init", device.index if device.index is not None else torch.cuda.current_device())
+        self.err = torch.zeros(4, dtype=torch.int32, device=device)
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    @classmethod
+    def get(cls, device):
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        rt = cls._by_device.get(device)
+        if rt is None:
+            rt = cls._by_device[device] = Runtime(device)
+        return rt
+
+    def workspace(self, nbytes):
+        if self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def check(self):
+        """Host sync: raise if a persistent kernel reported an inter-workgroup wait timeout."""
+        e = self.err.tolist()
+        if e[0] != 0:
+            self.err.zero_()
+            raise RuntimeError(f"timeband_amd: persistent LSTM kernel reported error words {e}")
+
+
+def check_errors(device=None):
+    for dev, rt in list(Runtime._by_device.items()):
+        if device is None or torch.device(device) == dev:
+            rt.check()
+
+
+# ----------------------------------------------------------------------------------------------
+# LSTM layer
+# ----------------------------------------------------------------------------------------------
+class _LSTMLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train):
+        _need_cuda(x, w_ih, w_hh, b_ih, b_hh)
+        x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
+        B, T, In = x.shape
+        H = w_hh.shape[1]
+        if w_ih.shape != (4 * H, In) or w_hh.shape != (4 * H, H):
+            raise RuntimeError("lstm: weight shapes do not match the input")
+        lib = _lib.load()
+        if not lib.tb_lstm_supported(H):
+            raise RuntimeError(f"lstm: hidden size {H} is not supported by the HIP kernels "
+                               "(supported: 16, 32, 64, 128, 256, 512)")
+        rt = Runtime.get(x.device)
+        y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
+        gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=x.device)
+        cst = torch.empty(B, T, H, dtype=torch.float32, device=x.device) if train else None
+        nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 0)
+        ws = rt.workspace(nws)
+        _lib.call("tb_lstm_fwd", _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(y), _ptr(gates),
+                  _ptr(cst), B, T, In, H, int(train), _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+        if train:
+            ctx.save_for_backward(x, w_ih, w_hh, y, gates, cst)
+            ctx.dims = (B, T, In, H)
+            ctx.used = False
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.used:
+            raise RuntimeError("lstm: backward called twice (the gate stash is consumed in place)")
+        ctx.used = True
+        x, w_ih, w_hh, y, gates, cst = ctx.saved_tensors
+        B, T, In, H = ctx.dims
+        dy = _f32c(dy)
+        dev = x.device
+        rt = Runtime.get(dev)
+        lib = _lib.load()
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dw_ih = torch.empty_like(w_ih) if need[1] else None
+        dw_hh = torch.empty_like(w_hh) if need[2] else None
+        db_ih = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[3] else None
+        db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[4] else None
+        nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 1)
+        ws = rt.workspace(nws)
+        _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
+                  _ptr(dx), _ptr(dw_ih), _ptr(dw_hh), _ptr(db_ih), _ptr(db_hh), B, T, In, H, _ptr(ws), ws.numel(),
+                  _ptr(rt.err), _stream())
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None
+
+
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
+    """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H)."""
+    # grad mode is off inside Function.forward, so the stash decision is taken here
+    train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh)))
+    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train)
+
+
+def lstm_stack(x, lstm_module):
+    """Run x through the layers of a torch.nn.LSTM parameter container with the HIP kernels."""
+    for l in range(lstm_module.num_layers):
+        x = lstm_layer(x, getattr(lstm_module, f"weight_ih_l{l}"), getattr(lstm_module, f"weight_hh_l{l}"),
+                       getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"))
+    return x
+
+
+# ----------------------------------------------------------------------------------------------
+# Linear (+ activation)
+# ----------------------------------------------------------------------------------------------
+class _LinearActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        _need_cuda(x, W, b)
+        x, W = _f32c(x), _f32c(W)
+        b = _f32c(b) if b is not None else None
+        M, K = x.shape
+        N = W.shape[0]
+        if W.shape[1] != K:
+            raise RuntimeError("linear: weight shape does not match the input")
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _lib.call("tb_linear_act_fwd", _ptr(x), _ptr(W), _ptr(b), _ptr(y), M, K, N, act, _stream())
+        ctx.save_for_backward(x, W, y if act else None)
+        ctx.act = act
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        M, K = x.shape
+        N = W.shape[0]
+        dy = _f32c(dy)
+        dev = x.device
+        rt = Runtime.get(dev)
+        lib = _lib.load()
+        if ctx.act:
+            dz = torch.empty_like(dy)
+            _lib.call("tb_act_bwd", _ptr(dy), _ptr(y), _ptr(dz), dy.numel(), ctx.act, _stream())
+        else:
+            dz = dy
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dW = torch.empty_like(W) if need[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
+        ws = rt.workspace(lib.tb_linear_workspace_bytes(M, K, N))
+        _lib.call("tb_linear_bwd", _ptr(dz), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, N, _ptr(ws),
+                  ws.numel(), _stream())
+        return dx, dW, db, None
+
+
+def linear_act(x2d, W, b, act=ACT_NONE):
+    """act(x2d @ W.T + b) for a 2-D x."""
+    return _LinearActFn.apply(x2d, W, b, act)
+
+
+# ----------------------------------------------------------------------------------------------
+# Losses
+# ----------------------------------------------------------------------------------------------
+def _world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def _loss_sums(Dy, DGx, tru, pred, rt):
+    lib = _lib.load()
+    sums = torch.empty(8, dtype=torch.float64, device=rt.device)
+    ws = rt.workspace(lib.tb_loss_workspace_bytes())
+    _lib.call("tb_loss_sums", _ptr(Dy), 0 if Dy is None else Dy.numel(), _ptr(DGx),
+              0 if DGx is None else DGx.numel(), _ptr(tru), _ptr(pred), 0 if pred is None else pred.numel(),
+              _ptr(sums), _ptr(ws), ws.numel(), _stream())
+    if _world() > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums)          # the gradient-penalty norm is batch-global (loss.py:136-141)
+    return sums
+
+
+class _DisLossFn(torch.autograd.Function):
+    """TIMEBANDLoss.dis_loss (loss.py:106-119): returns (total, out[8]); out is not differentiable."""
+
+    @staticmethod
+    def forward(ctx, Dy, DGx, tru, pred, critic, gp_w, running):
+        _need_cuda(Dy, DGx, tru, pred)
+        Dy, DGx = _f32c(Dy), _f32c(DGx)
+        rt = Runtime.get(Dy.device)
+        W = _world()
+        if critic:
+            tru, pred = _f32c(tru), _f32c(pred)
+            sums = _loss_sums(Dy, DGx, tru, pred, rt)
+        else:
+            sums = _loss_sums(Dy, DGx, None, None, rt)
+        out = torch.empty(8, dtype=torch.float32, device=Dy.device)
+        nP = float(pred.numel() * W) if critic else 1.0
+        batch = float(tru.shape[0] * W) if critic else 1.0
+        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, float(Dy.numel() * W), float(DGx.numel() * W),
+                  nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), _ptr(None if critic else running), _stream())
+        ctx.critic, ctx.gp_w, ctx.W = critic, gp_w, W
+        ctx.save_for_backward(Dy, DGx, tru if critic else None, pred if critic else None, sums)
+        total = torch.empty((), dtype=torch.float32, device=out.device)
+        total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gout):
+        Dy, DGx, tru, pred, sums = ctx.saved_tensors
+        W = ctx.W
+        up = _f32c(gtotal)
+        dDy = torch.empty_like(Dy) if ctx.needs_input_grad[0] else None
+        dDGx = torch.empty_like(DGx) if ctx.needs_input_grad[1] else None
+        wgan = 1 if ctx.critic else 0
+        if dDy is not None:
+            _lib.call("tb_gan_loss_grad", _ptr(Dy), Dy.numel(), float(Dy.numel() * W), 1, wgan, _ptr(up), _ptr(dDy),
+                      _stream())
+        if dDGx is not None:
+            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), float(DGx.numel() * W), 0, wgan, _ptr(up),
+                      _ptr(dDGx), _stream())
+        dpred = None
+        if ctx.critic and ctx.needs_input_grad[3]:
+            dpred = torch.empty_like(pred)
+            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), float(pred.numel() * W),
+                      float(tru.shape[0] * W), _ptr(sums), 0.0, 0.0, float(ctx.gp_w), _ptr(up), _ptr(dpred), 0,
+                      _stream())
+        return dDy, dDGx, None, dpred, None, None, None
+
+
+class _GenLossFn(torch.autograd.Function):
+    """TIMEBANDLoss.gen_loss (loss.py:93-104): adversarial term with the FAKE label + l1 + l2 + gp."""
+
+    @staticmethod
+    def forward(ctx, tru, pred, DGx, l1_w, l2_w, gp_w, running):
+        _need_cuda(tru, pred, DGx)
+        tru, pred, DGx = _f32c(tru), _f32c(pred), _f32c(DGx)
+        rt = Runtime.get(pred.device)
+        W = _world()
+        sums = _loss_sums(None, DGx, tru, pred, rt)
+        out = torch.empty(8, dtype=torch.float32, device=pred.device)
+        _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, float(DGx.numel() * W), float(pred.numel() * W),
+                  float(tru.shape[0] * W), float(l1_w), float(l2_w), float(gp_w), _ptr(out), _ptr(running), _stream())
+        ctx.w = (l1_w, l2_w, gp_w)
+        ctx.W = W
+        ctx.save_for_backward(tru, pred, DGx, sums)
+        total = torch.empty((), dtype=torch.float32, device=out.device)
+        total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
+        ctx.mark_non_differentiable(out)
+        return total, out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gout):
+        tru, pred, DGx, sums = ctx.saved_tensors
+        l1_w, l2_w, gp_w = ctx.w
+        W = ctx.W
+        up = _f32c(gtotal)
+        dpred = dDGx = None
+        if ctx.needs_input_grad[1]:
+            dpred = torch.empty_like(pred)
+            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), float(pred.numel() * W),
+                      float(tru.shape[0] * W), _ptr(sums), float(l1_w), float(l2_w), float(gp_w), _ptr(up),
+                      _ptr(dpred), 0, _stream())
+        if ctx.needs_input_grad[2]:
+            dDGx = torch.empty_like(DGx)
+            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), float(DGx.numel() * W), 0, 0, _ptr(up), _ptr(dDGx),
+                      _stream())
+        return None, dpred, dDGx, None, None, None, None
+
+
+def dis_loss(Dy, DGx, tru=None, pred=None, critic=False, gp_w=0.0, running=None):
+    return _DisLossFn.apply(Dy, DGx, tru, pred, critic, gp_w, running)
+
+
+def gen_loss(tru, pred, DGx, l1_w, l2_w, gp_w, running=None):
+    return _GenLossFn.apply(tru, pred, DGx, l1_w, l2_w, gp_w, running)
+
+
+# ----------------------------------------------------------------------------------------------
+# data side
+# ----------------------------------------------------------------------------------------------
+def window_gather(series, target_cols, first, nwin, To, Tf, stride=1, starts=None):
+    """enc (nwin,To,E), dec (nwin,Tf,V) from the device-resident normalised series (len,E)."""
+    _need_cuda(series, target_cols)
+    E = series.shape[1]
+    V = target_cols.numel()
+    enc = torch.empty(nwin, To, E, dtype=torch.float32, device=series.device)
+    dec = torch.empty(nwin, Tf, V, dtype=torch.float32, device=series.device)
+    if starts is not None:
+        lo, hi = int(starts.min()), int(starts.max())
+        if lo - To < 0 or hi + Tf > series.shape[0]:
+            raise RuntimeError("window_gather: a window leaves the series")
+    _lib.call("tb_window_gather", _ptr(series), series.shape[0], E, _ptr(starts), int(first), int(stride), nwin,
+              To, Tf, _ptr(target_cols), V, _ptr(enc), _ptr(dec), _stream())
+    return enc, dec
+
+
+def denormalize(x, dmin, dmax):
+    _need_cuda(x, dmin, dmax)
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    _lib.call("tb_denormalize", _ptr(x), x.numel(), x.shape[-1], _ptr(dmin), _ptr(dmax), _ptr(out), _stream())
+    return out
+
+
+def band_update(pden, hist_in, nhist, hist_out, band_width):
+    B, Tf, V = pden.shape
+    R = B + Tf - 1
+    mk = lambda: torch.empty(R, V, dtype=torch.float64, device=pden.device)
+    med, sd, lower, upper = mk(), mk(), mk(), mk()
+    _lib.call("tb_band_update", _ptr(pden), B, Tf, V, _ptr(hist_in), int(nhist), _ptr(hist_out), float(band_width),
+              _ptr(med), _ptr(sd), _ptr(lower), _ptr(upper), _stream())
+    return med, lower, upper
+
+
+VARIANTS = {"trainer": 0, "cleaner": 1, "predictor": 2}
+
+
+def adjust_scan(variant, seed, reals, preds, masks, lower, upper, a, b):
+    n, V = preds.shape
+    target = torch.empty(n, V, dtype=torch.float64, device=preds.device)
+    _lib.call("tb_adjust_scan", VARIANTS[variant], _ptr(seed), _ptr(reals), _ptr(preds), _ptr(masks), _ptr(lower),
+              _ptr(upper), n, V, float(a), float(b), _ptr(target), _stream())
+    return target
+
+
+def metrics(reals, preds, masks, running=None):
+    out = torch.empty(3, dtype=torch.float64, device=preds.device)
+    _lib.call("tb_metrics", _ptr(reals), _ptr(preds), _ptr(masks), preds.numel(), _ptr(out), _ptr(running), _stream())
+    return out
+
+
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):
+    _lib.call("tb_adam_step", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), b1, b2, eps, int(step),
+              _stream())
+
+
+def rmsprop_step(p, g, sq, lr, alpha=0.99, eps=1e-8, fresh=False):
+    _lib.call("tb_rmsprop_step", _ptr(p), _ptr(g), _ptr(sq), p.numel(), float(lr), alpha, eps, int(fresh), _stream())

@@ -1,0 +1,99 @@
+"""Fused Adam / RMSprop over ONE flat buffer per network (reference schedule:
+source/trainer.py:95-98 -- Adam re-created every epoch; :143-144 -- RMSprop re-created every batch).
+
+`flatten(module)` re-points every parameter (and its .grad) at a slice of one contiguous fp32
+buffer, so an optimizer step is one kernel launch and a data-parallel gradient exchange is one
+all-reduce with no packing.  Stock torch.optim optimizers still work on the same parameters.
+"""
+import torch
+
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module):
+        params = [p for p in module.parameters()]
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("flatten the module after moving it to the GPU")
+        n = sum(p.numel() for p in params)
+        self.data = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.params = params
+        off = 0
+        for p in params:
+            k = p.numel()
+            self.data[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.data[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+
+    def check(self):
+        """Parameters / grads must still alias the flat buffers (e.g. nobody set .grad = None)."""
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            if p.data.data_ptr() != self.data.data_ptr() + 4 * off:
+                raise RuntimeError("a parameter no longer aliases the flat buffer (module.to()/load after flatten?)")
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + k].view(p.shape)
+            off += k
+
+
+def flatten(module) -> FlatParams:
+    fp = getattr(module, "_tb_flat", None)
+    if fp is None:
+        fp = FlatParams(module)
+        object.__setattr__(module, "_tb_flat", fp)
+    else:
+        fp.check()
+    return fp
+
+
+class _FlatOptimizer:
+    def __init__(self, module, lr):
+        self.flat = flatten(module)
+        self.lr = lr
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat.check()
+        self.flat.grad.zero_()
+
+    def all_reduce_grads(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat.grad)      # sum: the loss kernels already divide by GLOBAL counts
+
+
+class FusedAdam(_FlatOptimizer):
+    """torch.optim.Adam defaults (betas .9/.999, eps 1e-8)."""
+
+    def __init__(self, module, lr, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(module, lr)
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+        self.t = 0
+
+    def step(self):
+        self.t += 1
+        ops.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
+                      self.eps)
+
+
+class FusedRMSprop(_FlatOptimizer):
+    """torch.optim.RMSprop defaults (alpha .99, eps 1e-8, no momentum)."""
+
+    def __init__(self, module, lr, alpha=0.99, eps=1e-8):
+        super().__init__(module, lr)
+        self.alpha, self.eps = alpha, eps
+        self.sq = None          # allocated only if the optimizer outlives one step
+
+    def step(self):
+        if self.sq is None:
+            self.sq = torch.empty_like(self.flat.data)
+            ops.rmsprop_step(self.flat.data, self.flat.grad, self.sq, self.lr, self.alpha, self.eps, fresh=True)
+        else:
+            ops.rmsprop_step(self.flat.data, self.flat.grad, self.sq, self.lr, self.alpha, self.eps, fresh=False)
