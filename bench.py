@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the LSTM-GAN G+D training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one Gen-A training iteration (reference source/trainer.py:142-194) on one batch of
+synthetic windows: window gather from the HBM-resident series, critic step (critic=1, batch =
+forecast_len windows, fresh RMSprop), discriminator phase (+Adam), generator phase (+Adam) and,
+for N > 1, the gradient / loss-sum all-reduces.  Workload = BASELINE.json configs[1]: 32 variables
+(+4 time features), window 128, hidden 256, 1 layer, batch 512 PER GPU (weak scaling).  All
+arithmetic is float32 (exact-fp32 MFMA): the parity mode IS the measured mode.
+
+Rank 0 prints ONE JSON line (contract in the task description) carrying `roofline` (dominant
+kernel, HIP-event timed on its own stream inside the timed region) and, at N=1, `cpu_baseline`
+(the stock-PyTorch CPU port of the same iteration on the host cores, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: V, time features, To, Tf, H, L, batch per GPU, series length
+    "cfg1": dict(V=7, NT=4, To=48, Tf=48, H=64, L=1, B=1024, N=20000),
+    "cfg2": dict(V=32, NT=4, To=128, Tf=128, H=256, L=1, B=512, N=100000),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algo_bytes_per_window(V, NT, To, Tf, H, L, **_):
+    """per LSTM layer fwd+bwd = 4*T*(3*in + 12*h) bytes; one iteration runs every G
+    layer 2x and every D layer 3x (critic excluded, heads/losses/optimizers excluded)."""
+    E = V + NT
+    g = 0
+    for (i, h) in ((E, H // 4), (H // 4, H // 2), (H // 2, H)):
+        g += 4 * To * (3 * i + 12 * h) + (L - 1) * 4 * To * (3 * h + 12 * h)
+    d = 4 * Tf * (3 * V + 12 * H) + (L - 1) * 4 * Tf * (3 * H + 12 * H)
+    return 2 * g + 3 * d
+
+
+class _Log:
+    def info(self, *a, **k):
+        pass
+
+    warn = debug = info
+
+
+def build(cfg, device, seed=31):
+    from timeband_amd import synthetic
+    from timeband_amd.dataset import TIMEBANDDataset
+    from timeband_amd.loss import TIMEBANDLoss
+    from timeband_amd.metric import TIMEBANDMetric
+    from timeband_amd.model import TIMEBANDModel
+    from timeband_amd.trainer import TIMEBANDTrainer
+    from timeband_amd.utils.initiate import seeding
+    seeding(seed)
+    V, To, Tf, H, L, B, N = (cfg[k] for k in ("V", "To", "Tf", "H", "L", "B", "N"))
+    log = _Log()
+    core = dict(logger=log, device=device, batch_size=B, observed_len=To, forecast_len=Tf, directory="", data_name="synthetic")
+    values = synthetic.make_series(N, V, seed=seed)
+    tfeat = synthetic.time_features(N + Tf)
+    ds = TIMEBANDDataset.from_arrays(values, tfeat, {**core, "stride": 1, "split_rate": 0.9, "min_valid_scale": 2,
+                                                     "sliding_step": 0})
+    trainset, validset = ds.prepare_dataset()
+    models = TIMEBANDModel({**core, "save_opt": False, "load_opt": False, "best_score": 50.0, "hidden_dim": H,
+                            "layers_num": L, "models_path": "/tmp/timeband_models"})
+    models.initiate(ds.dims)
+    losses = TIMEBANDLoss({**core, "l1_weight": 50, "l2_weight": 50, "gp_weight": 50})
+    metric = TIMEBANDMetric(core)
+    trainer = TIMEBANDTrainer({**core, "models": dict(reload=False, reload_interval=50, save_interval=10),
+                               "critic": 1, "epochs": 1,
+                               "learning_rate": dict(base=2e-4, decay=0.9, gammaD=1.0, gammaG=1.0),
+                               "band_width": 1, "missing_gamma": 0.2, "anomaly_gamma": 0.0, "print_interval": 1},
+                              ds, models, metric, losses, None)
+    trainer.new_epoch()
+    return ds, trainset, trainer
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full", action="store_true", help="also time band/adjust/scores inside the step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = CONFIGS[args.config]
+    ds, trainset, trainer = build(cfg, device)
+    B = cfg["B"]
+    from timeband_amd import _lib, ops
+    lib = _lib.load()
+    nbatches = len(trainset) // (B * world)
+    if nbatches < 1:
+        raise SystemExit("series too short for this batch / world size")
+
+    def step(i):
+        g0 = (i % nbatches) * B * world + rank * B      # this rank's contiguous shard of global batch i
+        batch = trainset.gather(g0, B)
+        fake = trainer.iteration(batch["encoded"], batch["decoded"], training=True)
+        if args.full:
+            trainer.post.idx = g0
+            trainer.metric.update(*trainer.post.step(fake)[:3])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    ops.check_errors(device)
+    kids = {"lstm_fwd": _lib.K_LSTM_FWD, "lstm_bwd": _lib.K_LSTM_BWD, "gemm": _lib.K_GEMM}
+    for k in kids.values():
+        lib.tb_prof_enable(k, 1)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.check_errors(device)
+    prof = {}
+    for name, k in kids.items():
+        n, ms, by = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+        lib.tb_prof_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by))
+        lib.tb_prof_enable(k, 0)
+        prof[name] = dict(launches=n.value, total_ms=ms.value, algo_bytes=by.value)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        windows = B * world * args.steps
+        value = windows / dt
+        dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: prof[k]["total_ms"])
+        p = prof[dom]
+        achieved = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9 if p["total_ms"] > 0 else 0.0
+        abw = algo_bytes_per_window(**cfg)
+        out = {
+            "metric": "G+D training windows/sec", "value": round(value, 2), "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: LSTM-GAN G+D iteration (critic=1 + D phase + G phase), "
+                                   f"V={cfg['V']} E={cfg['V'] + cfg['NT']} window={cfg['To']} hidden={cfg['H']} "
+                                   f"layers={cfg['L']} batch={B}/GPU", "global_batch": B * world,
+                       "parallelism": f"dp{world}", "full_iteration": bool(args.full)},
+            "roofline": {"bound": "hbm", "kernel": f"{dom}_kernel (persistent recurrent, all LSTM layers)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "launches": p["launches"],
+                         "avg_launch_ms": round(p["total_ms"] / max(1, p["launches"]), 4),
+                         "algo_bytes_per_launch": round(p["algo_bytes"] / max(1, p["launches"]), 1)},
+            "step_hbm_roofline": {"algo_bytes_per_window": abw,
+                                  "frac": round(abw * value / world / (HBM_PEAK_GBS * 1e9), 5)},
+            "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in prof.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.torch_cpu_port import time_cpu_baseline
+            threads = min(16, os.cpu_count() or 1)
+            iters = 3 if args.config == "cfg2" else 10
+            wps, spi, nthr = time_cpu_baseline(cfg["V"], cfg["V"] + cfg["NT"], cfg["To"], cfg["Tf"], cfg["H"], cfg["L"],
+                                               B, iters=iters, warmup=1, threads=threads)
+            out["cpu_baseline"] = {"value": round(wps, 2), "unit": "windows/s", "cores": nthr, "kind": "port",
+                                   "sample": f"{iters} timed + 1 warm-up iterations of the same workload "
+                                             f"(batch {B}, critic batch {cfg['Tf']}), stock PyTorch CPU ops, "
+                                             f"{spi:.2f} s/iteration"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,9 +28,10 @@ const char* tb_last_error(void);
 int tb_init(int device);
 int tb_device_cus(void);
 /* HIP-event timing of one kernel family (0 gemm, 1 lstm_fwd, 2 lstm_bwd, 3 loss, 4 optim,
- * 5 gather, 6 band) on the stream it runs on; read after a device synchronise. */
+ * 5 gather, 6 band) on the stream it runs on; read after a device synchronise.  algo_bytes = the
+ * SURVEY.md 8(d) algorithmic bytes of the timed launches (LSTM kernels only). */
 int tb_prof_enable(int kernel_id, int on);
-int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host);
+int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host, double* algo_bytes_host);
 
 /* ---- LSTM layer (torch.nn.LSTM, one layer, batch_first, zero initial state) --------------------
  * Reference call sites: source/utils/lstm_layer.py:31-33,44-46 (generator lstm0/1/2) and :75,83

@@ -265,3 +265,28 @@ def test_clean_and_predict(trained):
     np.testing.assert_allclose(np.concatenate([lo, up], axis=1), z["clean.bands"], rtol=2e-4, atol=2e-4)
     out2, _, _ = O.clean(pG, s, B, L, "predictor", 1.0, 0.2, 0.3)
     np.testing.assert_allclose(out2, z["predict.outputs"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["uneven", "twolayer"])
+def test_torch_port_matches_reference(golden_dir, name):
+    """The stock-PyTorch CPU port (bench.py's cpu_baseline) against the same golden vectors."""
+    import torch
+    from oracle import torch_cpu_port as P
+    torch.set_num_threads(1)
+    z = load(golden_dir, f"scenario_{name}.npz")
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    D, G = P.PortD(V, H, L), P.PortG(E, V, To, Tf, H, L)
+    D.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netD").items()})
+    G.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netG").items()})
+    tr = P.PortTrainer(D, G, lr=float(z["lr"]))
+    t = lambda k: torch.tensor(z[k])
+    errD, errG, fake = tr.iteration(t("x"), t("y"), t("xc"), t("yc"))
+    assert relerr(errD, z["it0.dphase.errD"]) < 1e-6
+    assert relerr(errG, z["it0.gphase.errG"]) < 1e-6
+    assert relerr(fake.numpy(), z["it0.fake_y"]) < 1e-6
+    for it in (1, 2):
+        errD, errG, fake = tr.iteration(t(f"it{it}.x"), t(f"it{it}.y"), t(f"it{it}.xc"), t(f"it{it}.yc"))
+        assert relerr(errG, z[f"it{it}.gphase.errG"]) < 1e-5
+    want = sub(z, "it2.gphase.after.netG")
+    for k, v in G.state_dict().items():
+        assert np.abs(v.numpy() - want[k]).max() < 1e-7, k

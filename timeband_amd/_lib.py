@@ -27,7 +27,7 @@ SIGNATURES = {
     "tb_init": (I, [I]),
     "tb_device_cus": (I, []),
     "tb_prof_enable": (I, [I, I]),
-    "tb_prof_read": (I, [I, C.POINTER(I), C.POINTER(D)]),
+    "tb_prof_read": (I, [I, C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
     "tb_lstm_supported": (I, [I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
@@ -64,6 +64,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m timeband_amd.build` "
             "(there is no CPU/PyTorch fallback for the hot path)")
+    # torch must be imported first: the wheel bundles its own HIP runtime, and our library has to bind
+    # to THAT copy (same soname) -- loading /opt/rocm's runtime first leaves two runtimes in the process
+    # and torch then sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the .so lacks a declared symbol

@@ -20,6 +20,7 @@ struct Prof {
   hipEvent_t beg[MAXE], end[MAXE];
   int n = 0, created = 0;
   bool open = false;
+  double bytes = 0.0;
 };
 Prof g_prof[TB_K_COUNT];
 }  // namespace
@@ -48,21 +49,22 @@ int tb_num_cus() {
   return g_cus;
 }
 
-void tb_prof_begin(int id, hipStream_t s) {
+void tb_prof_begin(int id, hipStream_t s, double algo_bytes) {
   Prof& p = g_prof[id];
   if (!p.on || p.n >= Prof::MAXE) return;
   if (p.n >= p.created) {
     if (hipEventCreate(&p.beg[p.n]) != hipSuccess || hipEventCreate(&p.end[p.n]) != hipSuccess) return;
     p.created = p.n + 1;
   }
-  hipEventRecord(p.beg[p.n], s);
+  (void)hipEventRecord(p.beg[p.n], s);
   p.open = true;
+  p.bytes += algo_bytes;
 }
 
 void tb_prof_end(int id, hipStream_t s) {
   Prof& p = g_prof[id];
   if (!p.on || !p.open) return;
-  hipEventRecord(p.end[p.n], s);
+  (void)hipEventRecord(p.end[p.n], s);
   p.n++;
   p.open = false;
 }
@@ -92,11 +94,12 @@ int tb_prof_enable(int kernel_id, int on) {
   g_prof[kernel_id].on = on != 0;
   g_prof[kernel_id].n = 0;
   g_prof[kernel_id].open = false;
+  g_prof[kernel_id].bytes = 0.0;
   return TB_OK;
 }
 
 // Call after a device synchronize.  Returns the number of timed launches; total_ms = sum of durations.
-int tb_prof_read(int kernel_id, int* count, double* total_ms) {
+int tb_prof_read(int kernel_id, int* count, double* total_ms, double* algo_bytes) {
   if (kernel_id < 0 || kernel_id >= TB_K_COUNT) return tb_set_error(TB_ERR_ARG, "prof: bad kernel id");
   Prof& p = g_prof[kernel_id];
   double tot = 0.0;
@@ -107,7 +110,9 @@ int tb_prof_read(int kernel_id, int* count, double* total_ms) {
   }
   if (count) *count = p.n;
   if (total_ms) *total_ms = tot;
+  if (algo_bytes) *algo_bytes = p.bytes;
   p.n = 0;
+  p.bytes = 0.0;
   return TB_OK;
 }
 

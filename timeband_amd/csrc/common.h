@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned tb_load_agent_u32(const unsigned* p) {
 }
 
 // profiling hooks (capi.hip): HIP-event timing of one kernel family on its own stream
-void tb_prof_begin(int kernel_id, hipStream_t s);
+void tb_prof_begin(int kernel_id, hipStream_t s, double algo_bytes = 0.0);
 void tb_prof_end(int kernel_id, hipStream_t s);
 
 enum TbKernelId {

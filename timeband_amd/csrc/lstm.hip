@@ -603,7 +603,8 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
                           nullptr, 0, s);
   if (rc) return rc;
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
-  tb_prof_begin(TB_K_LSTM_FWD, s);
+  // algorithmic bytes of one layer forward: read x, write h, write the 5h stash
+  tb_prof_begin(TB_K_LSTM_FWD, s, 4.0 * B * T * (train ? (in_dim + 6.0 * H) : (in_dim + 1.0 * H)));
   for (int c0 = 0; c0 < ncl_total; c0 += p.clusters_per_launch) {
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     FwdArgs a;
@@ -639,7 +640,8 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   int rc;
-  tb_prof_begin(TB_K_LSTM_BWD, s);
+  // algorithmic bytes of one layer backward: read 5h stash + dy, read x, write dx
+  tb_prof_begin(TB_K_LSTM_BWD, s, 4.0 * B * T * (2.0 * in_dim + 6.0 * H));
   for (int c0 = 0; c0 < ncl_total; c0 += p.clusters_per_launch) {
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     BwdArgs a;

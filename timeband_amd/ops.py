@@ -196,9 +196,26 @@ def linear_act(x2d, W, b, act=ACT_NONE):
 # ----------------------------------------------------------------------------------------------
 # Losses
 # ----------------------------------------------------------------------------------------------
+_REPLICATED = False
+
+
+class replicated:
+    """Context: every rank runs the SAME batch (e.g. a critic batch that does not divide by the
+    world size).  Losses then use local counts and nothing is all-reduced: the kernels are
+    deterministic, so all ranks take bit-identical steps."""
+
+    def __enter__(self):
+        global _REPLICATED
+        self._old, _REPLICATED = _REPLICATED, True
+
+    def __exit__(self, *exc):
+        global _REPLICATED
+        _REPLICATED = self._old
+
+
 def _world():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    if not _REPLICATED and dist.is_available() and dist.is_initialized():
         return dist.get_world_size()
     return 1
 

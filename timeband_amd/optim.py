@@ -62,8 +62,8 @@ class _FlatOptimizer:
         self.flat.grad.zero_()
 
     def all_reduce_grads(self):
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if ops._world() > 1:
+            import torch.distributed as dist
             dist.all_reduce(self.flat.grad)      # sum: the loss kernels already divide by GLOBAL counts
 
 

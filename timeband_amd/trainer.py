@@ -1,0 +1,190 @@
+"""TIMEBANDTrainer on the HIP hot path (reference source/trainer.py:18-305).
+
+Same constructor, config keys, `train` / `train_step` / `model_update` behaviour and step
+semantics as the reference's Gen-A trainer, including its quirks:
+  * critic loop with a FRESH RMSprop per batch and a non-detached fake_y (trainer.py:142-158);
+  * `zero_grad` of D and G once per iteration, before the D phase (:160-161), so the generator
+    step uses D-phase + G-phase gradients;
+  * Adam re-created every epoch (:95-98);
+  * generator adversarial term against the FAKE label (loss.py:94).
+What changes is where the work runs: windows are gathered on the device, losses / optimizers /
+band / adjust / scores are HIP kernels, and nothing is copied to the host inside the batch loop
+(the reference syncs on `.cpu()` and `.numpy()` every batch, trainer.py:202,223-234).
+Data parallel: one process per GPU, every rank holds the same parameters and steps on its
+contiguous shard of each global batch; gradients are summed with ONE all-reduce per network over
+the flat gradient buffer (RCCL over xGMI), the gradient-penalty norm with one 8-double all-reduce.
+"""
+import torch
+
+from . import ops
+from .loss import TIMEBANDLoss
+from .metric import TIMEBANDMetric
+from .model import TIMEBANDModel
+from .optim import FusedAdam, FusedRMSprop
+from .postprocess import BandAdjust
+
+
+class TIMEBANDTrainer:
+    def __init__(self, config: dict, dataset, models: TIMEBANDModel, metric: TIMEBANDMetric,
+                 losses: TIMEBANDLoss, dashboard=None) -> None:
+        self.logger = config["logger"]
+        self.dataset, self.models, self.metric, self.losses, self.dashboard = dataset, models, metric, losses, dashboard
+        self.set_config(config)
+        self.forecast_len = self.dataset.forecast_len
+        self.post = BandAdjust(dataset, "trainer", self.band_width, self.missing_gamma, self.anomaly_gamma)
+        self.optimD = self.optimG = None
+
+    def set_config(self, config: dict = None) -> None:
+        self.__dict__ = {**config, **self.__dict__}
+        lr = config["learning_rate"]
+        self.lr, self.lr_decay = lr["base"], lr["decay"]
+        self.lr_gammaG, self.lr_gammaD = lr["gammaG"], lr["gammaD"]
+        m = config["models"]
+        self.reload_option, self.reload_interval, self.save_interval = m["reload"], m["reload_interval"], m["save_interval"]
+        self.reload_counts = 0
+
+    # ------------------------------------------------------------------ epoch level
+    def model_update(self, epoch: int, score: float) -> None:
+        """Checkpoint / reload policy of trainer.py:65-85."""
+        if score < self.models.best_score:
+            self.reload_counts = -1
+            self.models.best_score = score
+            self.models.save(f"{score:.3f}", best=True)
+        if (epoch + 1) % self.save_interval == 0:
+            self.models.save()
+        if self.reload_option:
+            self.reload_counts += 1
+            if self.reload_counts >= self.reload_interval:
+                self.reload_counts = 0
+                self.logger.info(f" - Learning rate decay {self.lr} to {self.lr * self.lr_decay}")
+                self.lr *= self.lr_decay
+                self.models.load("BEST")
+
+    def new_epoch(self):
+        """Fresh Adam for D and G, idx = 0, empty band state (trainer.py:95-102)."""
+        self.optimD = FusedAdam(self.models.netD, self.lr * self.lr_gammaD)
+        self.optimG = FusedAdam(self.models.netG, self.lr * self.lr_gammaG)
+        self.idx = 0
+        self.pred_initate()
+
+    def pred_initate(self):
+        self.post.reset()
+
+    def train(self, trainset, validset) -> None:
+        self.logger.info("Train the model")
+        valid_score, epoch = float("inf"), -1
+        for epoch in range(self.epochs):
+            self.new_epoch()
+            train_score = self.train_step(epoch, trainset, training=True)
+            valid_score = self.train_step(epoch, validset, training=False)
+            if (epoch + 1) % self.print_interval == 0:
+                self.logger.info(f"[Ep {epoch + 1}] T ({train_score:.4f}) V ({valid_score:.4f})", level=1)
+            if train_score - valid_score < train_score * 0.25:
+                self.model_update(epoch, valid_score)
+        self.model_update(epoch, valid_score)
+
+    # ------------------------------------------------------------------ one iteration of the hot path
+    def critic_step(self, true_x, true_y):
+        """trainer.py:143-158 for one draw."""
+        netD, netG = self.models.netD, self.models.netG
+        fake_y = netG(true_x)
+        self._critic_opt.zero_grad()
+        Dy, DGx = netD(true_y), netD(fake_y)
+        errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx, critic=True)
+        errD.backward()
+        self._critic_opt.all_reduce_grads()
+        self._critic_opt.step()
+
+    @staticmethod
+    def _shard_critic(cx, cy):
+        """Data parallel: every rank draws the same critic batch (same numpy seed).  If its size
+        divides by the world size each rank keeps its contiguous slice (sharded, all-reduced);
+        otherwise all ranks run the whole batch redundantly (replicated, nothing reduced)."""
+        W = ops._world()
+        if W == 1:
+            return cx, cy, True
+        import torch.distributed as dist
+        n, r = cx.shape[0], dist.get_rank()
+        if n % W:
+            return cx, cy, False
+        k = n // W
+        return cx[r * k:(r + 1) * k].contiguous(), cy[r * k:(r + 1) * k].contiguous(), True
+
+    def iteration(self, true_x, true_y, training=True, critic_batches=None):
+        """trainer.py:142-194.  `critic_batches`: iterable of (x, y) critic draws (default: `critic`
+        draws from dataset.get_random()).  Returns the G-phase fake_y."""
+        netD, netG = self.models.netD, self.models.netG
+        if training:
+            self._critic_opt = FusedRMSprop(netD, self.lr * self.lr_gammaD)
+            if critic_batches is None:
+                critic_batches = (self.dataset.get_random() for _ in range(self.critic))
+            for cx, cy in critic_batches:
+                cx, cy, shared = self._shard_critic(cx, cy)
+                if shared:
+                    self.critic_step(cx, cy)
+                else:
+                    with ops.replicated():
+                        self.critic_step(cx, cy)
+        self.optimD.zero_grad()
+        self.optimG.zero_grad()
+        # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
+        with torch.set_grad_enabled(training):
+            fake_y = netG(true_x)
+            Dy, DGx = netD(true_y), netD(fake_y)
+            errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx)
+        if training:
+            errD.backward()
+            self.optimD.all_reduce_grads()
+            self.optimD.step()
+        # generator phase
+        with torch.set_grad_enabled(training):
+            fake_y = netG(true_x)
+            DGx = netD(fake_y)
+            errG = self.losses.gen_loss(true_y, fake_y, DGx)
+        if training:
+            errG.backward()
+            self.optimG.all_reduce_grads()
+            self.optimG.step()
+        return fake_y.detach()
+
+    def train_step(self, epoch: int, dataset, training: bool = True):
+        """One pass over `dataset` (any iterable of {"encoded","decoded"} batches); returns the mean
+        NMAE like trainer.py:236.  One host sync, at the end."""
+        if self.optimD is None:
+            self.new_epoch()
+        self.losses.init_loss()
+        self.metric.init_score()
+        self.post.restart_pass()
+        dev = self.device
+        i = -1
+        for i, data in enumerate(dataset):
+            true_x = data["encoded"].to(dev)
+            true_y = data["decoded"].to(dev)
+            fake_y = self.iteration(true_x, true_y, training)
+            reals, preds, masks, lower, upper, target = self.post.step(fake_y)
+            self.idx = self.post.idx
+            if self.dashboard is not None and getattr(self.dashboard, "vis_opt", False):
+                self.dashboard.vis(true_y.shape[0], reals.cpu().numpy(), preds.cpu().numpy(), lower.cpu().numpy(),
+                                   upper.cpu().numpy(), target.cpu().numpy())
+            self.metric.update(reals, preds, masks)
+        if i < 0:
+            return float("nan")
+        ops.check_errors(dev)
+        self.logger.info(desc(training, epoch, self.metric.score(i), self.losses.loss(i)), level=0)
+        return self.metric.nmae / (i + 1)
+
+    # kept for API parity with the reference (trainer.py:238-287); they run the same HIP kernels
+    def adjust(self, output, preds, masks, lower, upper):
+        dev = self.device
+        t = lambda a, dt=torch.float64: torch.as_tensor(a).to(device=dev, dtype=dt).contiguous()
+        out = t(output)
+        tgt = ops.adjust_scan("trainer", out[0].contiguous(), out[1:].contiguous(), t(preds), t(masks, torch.int32),
+                              t(lower), t(upper), self.missing_gamma, self.anomaly_gamma)
+        return tgt.cpu().numpy()
+
+
+def desc(training, epoch, score, losses):
+    process = "Train" if training else "Valid"
+    return (f"[{process} e{epoch + 1:4d}] (NMAE Score {score['NMAE']} NME {score['NME']} / RMSE {score['RMSE']} ) "
+            f"D {losses['D']} ( R {losses['R']} F {losses['F']} ) "
+            f"G {losses['G']} ( G {losses['G_']} L1 {losses['L1']} L2 {losses['L2']} GP {losses['GP']} )")
