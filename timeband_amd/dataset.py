@@ -173,12 +173,12 @@ class TIMEBANDDataset:
         self.encode_shape = (self.batch_size, self.observed_len, self.encode_dim)
         self.decode_shape = (self.batch_size, self.forecast_len, self.decode_dim)
         # the reference casts each float64 window to float32 (utils/dataset.py:19-20): same values
-        self.series_dev = torch.tensor(norm64, dtype=torch.float64).to(torch.float32).to(dev)
+        self.series_dev = torch.tensor(np.ascontiguousarray(norm64), dtype=torch.float64).to(torch.float32).to(dev).contiguous()
         self.tcols_dev = torch.tensor(target_cols, dtype=torch.int32, device=dev)
-        self.forecast_dev = self.forecast.to(dev)
-        self.observed_dev = self.observed.to(dev)
-        self.missing_dev = torch.tensor(np.asarray(self.missing), dtype=torch.int32, device=dev)
-        self.dmin_dev, self.dmax_dev = self.decode_min.to(dev), self.decode_max.to(dev)
+        self.forecast_dev = self.forecast.to(dev).contiguous()
+        self.observed_dev = self.observed.to(dev).contiguous()
+        self.missing_dev = torch.tensor(np.ascontiguousarray(self.missing), dtype=torch.int32, device=dev).contiguous()
+        self.dmin_dev, self.dmax_dev = self.decode_min.to(dev).contiguous(), self.decode_max.to(dev).contiguous()
 
     @classmethod
     def from_arrays(cls, values, tfeat, config: dict, target_cols=None):

@@ -336,6 +336,8 @@ def gen_loss(tru, pred, DGx, l1_w, l2_w, gp_w, running=None):
 def window_gather(series, target_cols, first, nwin, To, Tf, stride=1, starts=None):
     """enc (nwin,To,E), dec (nwin,Tf,V) from the device-resident normalised series (len,E)."""
     _need_cuda(series, target_cols)
+    if not series.is_contiguous() or series.dtype != torch.float32 or target_cols.dtype != torch.int32:
+        raise RuntimeError("window_gather: series must be contiguous float32, target_cols int32")
     E = series.shape[1]
     V = target_cols.numel()
     enc = torch.empty(nwin, To, E, dtype=torch.float32, device=series.device)
@@ -351,14 +353,19 @@ def window_gather(series, target_cols, first, nwin, To, Tf, stride=1, starts=Non
 
 def denormalize(x, dmin, dmax):
     _need_cuda(x, dmin, dmax)
-    x = _f32c(x)
+    x, dmin, dmax = _f32c(x), _c(dmin, torch.float64), _c(dmax, torch.float64)
     out = torch.empty_like(x)
     _lib.call("tb_denormalize", _ptr(x), x.numel(), x.shape[-1], _ptr(dmin), _ptr(dmax), _ptr(out), _stream())
     return out
 
 
 def band_update(pden, hist_in, nhist, hist_out, band_width):
+    _need_cuda(pden, hist_in, hist_out)
+    pden = _f32c(pden)
     B, Tf, V = pden.shape
+    for h in (hist_in, hist_out):
+        if h.shape != (Tf - 1, Tf, V) or not h.is_contiguous() or h.dtype != torch.float32:
+            raise RuntimeError("band_update: history buffers must be contiguous float32 (Tf-1,Tf,V)")
     R = B + Tf - 1
     mk = lambda: torch.empty(R, V, dtype=torch.float64, device=pden.device)
     med, sd, lower, upper = mk(), mk(), mk(), mk()
@@ -370,8 +377,21 @@ def band_update(pden, hist_in, nhist, hist_out, band_width):
 VARIANTS = {"trainer": 0, "cleaner": 1, "predictor": 2}
 
 
+def _c(t, dtype):
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def adjust_scan(variant, seed, reals, preds, masks, lower, upper, a, b):
+    _need_cuda(seed, reals, preds, masks, lower, upper)
+    f64 = torch.float64
+    seed, reals, preds, lower, upper = (_c(t, f64) for t in (seed, reals, preds, lower, upper))
+    masks = _c(masks, torch.int32)
     n, V = preds.shape
+    if reals.shape != (n, V) or masks.shape != (n, V) or lower.shape != (n, V) or upper.shape != (n, V) \
+            or seed.numel() != V:
+        raise RuntimeError("adjust_scan: shape mismatch")
     target = torch.empty(n, V, dtype=torch.float64, device=preds.device)
     _lib.call("tb_adjust_scan", VARIANTS[variant], _ptr(seed), _ptr(reals), _ptr(preds), _ptr(masks), _ptr(lower),
               _ptr(upper), n, V, float(a), float(b), _ptr(target), _stream())
@@ -379,6 +399,10 @@ def adjust_scan(variant, seed, reals, preds, masks, lower, upper, a, b):
 
 
 def metrics(reals, preds, masks, running=None):
+    _need_cuda(reals, preds, masks)
+    reals, preds, masks = _c(reals, torch.float64), _c(preds, torch.float64), _c(masks, torch.int32)
+    if reals.shape != preds.shape or masks.shape != preds.shape:
+        raise RuntimeError("metrics: shape mismatch")
     out = torch.empty(3, dtype=torch.float64, device=preds.device)
     _lib.call("tb_metrics", _ptr(reals), _ptr(preds), _ptr(masks), preds.numel(), _ptr(out), _ptr(running), _stream())
     return out
