@@ -101,11 +101,13 @@ int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, doub
  *   window w starts at row i = starts ? starts[w] : first + w*stride;
  *   enc[w] = series[i-To:i, :] (To,E); dec[w] = series[i:i+Tf, target_cols] (Tf,V).
  * tb_denormalize: source/dataset.py:229-242 (fp32 -> fp64 arithmetic -> fp32).
- * tb_band_update: predicts(), source/trainer.py:266-287 = cleaner.py:158-179 = predictor.py:134-155.
+ * tb_band_update: predicts(), source/trainer.py:266-287 = source/cleaner.py:158-179 =
+ *   source/predictor.py:134-155.
  *   pden (B,Tf,V) denormalised predictions; hist_in/hist_out (Tf-1,Tf,V) the predictions of the last
  *   Tf-1 windows before/after this batch (distinct buffers; nhist = valid windows in hist_in);
  *   med/sd/lower/upper (B+Tf-1,V) float64.
- * tb_adjust_scan: adjust(); variant 0 trainer.py:238-257, 1 cleaner.py:130-149, 2 predictor.py:106-125.
+ * tb_adjust_scan: adjust(); variant 0 source/trainer.py:238-257, 1 source/cleaner.py:130-149,
+ *   2 source/predictor.py:106-125.
  *   seed (V) = the row before reals[0]; reals/preds/lower/upper (n,V) float64; masks (n,V) int32.
  * tb_metrics: NME / NMAE / RMSE of source/metric.py:30-73 -> out[3] (+= running[3], nullable). */
 int tb_window_gather(const float* series, long series_len, int E, const long* starts, long first, long stride,

@@ -188,27 +188,35 @@ def discriminator_bwd(grads, dout, cache, need_dx=True):
 REAL_LABEL, FAKE_LABEL = F32(0.9), F32(0.1)     # loss.py:63-64
 
 
-def gan_loss(p, target_is_real, mode="lsgan"):
-    """loss.py:34-51.  Returns (loss, dloss/dp)."""
-    n = F32(p.size)
+def gan_loss(p, target_is_real, mode="lsgan", n_global=None):
+    """loss.py:34-51.  Returns (loss, dloss/dp).  n_global: element count of the GLOBAL batch when
+    `p` is one data-parallel shard (the returned loss is then this shard's share of the mean)."""
+    n = F32(p.size if n_global is None else n_global)
     if mode in ("lsgan", "vanilla"):
         t = REAL_LABEL if target_is_real else FAKE_LABEL
         d = p - t
-        return F32(np.mean(d * d, dtype=F32)), (2 * d / n).astype(p.dtype)
+        return F32(np.sum(d * d, dtype=np.float64) / n), (2 * d / n).astype(p.dtype)
     sgn = F32(-1.0) if target_is_real else F32(1.0)
-    return F32(sgn * np.mean(p, dtype=F32)), np.full(p.shape, sgn / n, p.dtype)
+    return F32(sgn * np.sum(p, dtype=np.float64) / n), np.full(p.shape, sgn / n, p.dtype)
 
 
-def recon_terms(true, pred, l1_w, l2_w, gp_w):
-    """loss.py:127-141: l1_w*SmoothL1 + l2_w*MSE + gp_w*(1-||true-pred||_2)^2/B and the
-    gradient of their sum wrt pred."""
+def recon_sums(true, pred):
+    """(sum SmoothL1(d), sum d^2) of one shard, d = pred - true; what data-parallel ranks all-reduce."""
     d = (pred - true).astype(pred.dtype)
-    N = F32(d.size)
-    B = F32(true.shape[0])
     ad = np.abs(d)
     hub = np.where(ad < 1, F32(0.5) * d * d, ad - F32(0.5))
-    l1 = F32(l1_w) * F32(np.sum(hub, dtype=np.float64) / N)
-    S = np.sum(d.astype(np.float64) ** 2)
+    return np.sum(hub, dtype=np.float64), np.sum(d.astype(np.float64) ** 2)
+
+
+def recon_terms(true, pred, l1_w, l2_w, gp_w, sums=None, n_global=None, batch_global=None):
+    """loss.py:127-141: l1_w*SmoothL1 + l2_w*MSE + gp_w*(1-||true-pred||_2)^2/B and the
+    gradient of their sum wrt pred.  sums / n_global / batch_global: the GLOBAL (all-reduced)
+    sums and counts when (true, pred) is one data-parallel shard."""
+    d = (pred - true).astype(pred.dtype)
+    N = F32(d.size if n_global is None else n_global)
+    B = F32(true.shape[0] if batch_global is None else batch_global)
+    Sh, S = recon_sums(true, pred) if sums is None else sums
+    l1 = F32(l1_w) * F32(Sh / N)
     l2 = F32(l2_w) * F32(S / N)
     n = np.sqrt(S)
     gp = F32(gp_w) * F32((1 - n) ** 2 / B)

@@ -1,0 +1,105 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/timeband_hip.h declares,
+the ctypes table matches the header, and the host-side logic that needs no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "timeband_hip.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = header_functions()
+    for must in ("tb_lstm_fwd", "tb_lstm_bwd", "tb_linear_act_fwd", "tb_linear_bwd", "tb_loss_sums",
+                 "tb_adam_step", "tb_rmsprop_step", "tb_window_gather", "tb_band_update", "tb_adjust_scan"):
+        assert must in names
+    text = open(HEADER).read()
+    # every block cites the reference file it replaces
+    for cite in ("source/utils/lstm_layer.py", "source/loss.py", "source/trainer.py", "source/dataset.py",
+                 "source/cleaner.py", "source/predictor.py", "source/metric.py"):
+        assert cite in text, cite
+
+
+def test_library_exports_every_declared_symbol():
+    from timeband_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -m timeband_amd.build"
+    lib = _lib.load()                      # binds every entry of SIGNATURES (AttributeError if missing)
+    declared = header_functions()
+    assert sorted(_lib.SIGNATURES) == declared, set(declared) ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.tb_version() >= 1           # host-only call, no GPU needed
+    assert lib.tb_lstm_supported(256) == 1 and lib.tb_lstm_supported(100) == 0
+    assert lib.tb_loss_workspace_bytes() > 0
+
+
+def test_product_path_has_no_oracle_import():
+    """Nothing under timeband_amd/ may import, call or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "timeband_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "timeband_oracle" not in src and "torch_cpu_port" not in src, f
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    import torch
+    from timeband_amd import ops
+    x = torch.zeros(2, 3, 4)
+    w = torch.zeros(64, 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.lstm_layer(x, w, torch.zeros(64, 16), torch.zeros(64), torch.zeros(64))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.linear_act(torch.zeros(4, 4), torch.zeros(2, 4), None)
+
+
+def test_interpolate_and_window_math_match_oracle():
+    from oracle import timeband_oracle as O
+    from timeband_amd.dataset import _interpolate, TIMEBANDDataset
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(50, 4))
+    a[rng.random((50, 4)) < 0.3] = np.nan
+    a[:3, 0] = np.nan          # leading gap -> backward fill
+    a[:, 3] = np.nan           # empty column -> zeros
+    np.testing.assert_array_equal(_interpolate(a), O.interpolate(a))
+    ds = TIMEBANDDataset.__new__(TIMEBANDDataset)
+    for n, To, Tf, stride in ((172, 24, 12, 1), (100, 10, 3, 1), (100, 10, 3, 2), (30, 20, 11, 1)):
+        ds.observed_len, ds.forecast_len, ds.stride, ds.data_length = To, Tf, stride, n
+        assert ds.n_windows() == len(O.window_starts(n, To, Tf, stride))
+
+
+def test_time_feature_order():
+    from timeband_amd import synthetic
+    tf = synthetic.time_features(30, enabled=("month", "weekday", "day", "hour"))
+    assert tf.shape == (30, 4)
+    assert list(tf[:3, 0]) == [0.0, 1.0, 2.0]       # hour first
+    assert tf[0, 1] == 4.0 and tf[0, 2] == 1.0 and tf[0, 3] == 1.0   # 2021-01-01: Friday, day 1, month 1
+
+
+def test_init_matches_reference_rng_order(golden_dir):
+    """Same seed -> bit-identical initial weights as the reference (D before G, model.py:56-57)."""
+    import torch  # noqa: F401
+    from timeband_amd.utils.lstm_layer import LSTMGenerator, LSTMDiscriminator
+    from timeband_amd.utils.initiate import seeding
+    for name in ("cfg1", "twolayer"):
+        z = np.load(os.path.join(golden_dir, f"scenario_{name}.npz"))
+        V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+        seeding(31)
+        netD = LSTMDiscriminator(V, H, L)
+        netG = LSTMGenerator(E, V, To, Tf, H, L)
+        for k, v in netD.state_dict().items():
+            assert np.array_equal(v.numpy(), z[f"init.netD.{k}"]), k
+        for k, v in netG.state_dict().items():
+            assert np.array_equal(v.numpy(), z[f"init.netG.{k}"]), k
