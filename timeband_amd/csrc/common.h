@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define TB_OK 0
 #define TB_ERR_ARG 1

@@ -92,19 +92,31 @@ __device__ __forceinline__ bool wait_members(const unsigned* flags, int NCL, int
   return *s_dead == 0;
 }
 
+__device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
+
+// element r0+rr of a 4-row accumulator, r0 = kp*RPW, without dynamic register indexing
+template <int KS>
+__device__ __forceinline__ float pick_row(const f32x4& v, int kp, int rr) {
+  if (KS == 1) return v[rr];
+  if (KS == 2) return kp ? v[2 + rr] : v[rr];
+  return kp == 0 ? v[0] : (kp == 1 ? v[1] : (kp == 2 ? v[2] : v[3]));
+}
+
 template <int H, int US, int KS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NUG = US / 16;          // 16-unit groups per member
   constexpr int NCL = H / US;           // members per cluster
   constexpr int KPER = H / KS;          // k range per wave
   constexpr int KG = KPER / 16;         // 16-wide k groups per wave
-  constexpr int NACT = NUG * KS;        // waves doing MFMA work
-  constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
+  constexpr int NACT = NUG * KS;        // waves doing work
+  constexpr int RPW = 4 / KS;           // accumulator rows each k-split partner finishes
+  constexpr int RED = KS > 1 ? KS * NUG * MT * 4 * 256 : 0;   // floats of k-split scratch
   static_assert(NACT <= 4 && KPER % 16 == 0 && H % US == 0, "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hL = smem;                                    // [MT][H/16][64][4]
-  float* red = smem + MT * H * 16;                     // [MT][NUG][KS-1][4][64][4]
+  float* red = smem + MT * H * 16;                     // [MT][NUG][KS][4][64][4]
   int* s_dead = reinterpret_cast<int*>(smem + MT * H * 16 + RED);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -113,7 +125,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   cluster_decode(a.nclusters, NCL, cl, j);
   const bool active = wave < NACT;
   const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
-  const bool owner = active && kp == 0;
   const int u = j * US + ug * 16 + col;                // hidden unit of this lane
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
@@ -132,26 +143,34 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         w[g][kg * 4 + 0] = v[0]; w[g][kg * 4 + 1] = v[1]; w[g][kg * 4 + 2] = v[2]; w[g][kg * 4 + 3] = v[3];
       }
   }
-  float c[MT][4];
+  // this wave finishes accumulator rows [kp*RPW, kp*RPW+RPW) of every 4-row group
+  float c[MT][RPW], pre[MT][4][RPW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) c[mt][r] = 0.f;
+    for (int rr = 0; rr < RPW; ++rr) {
+      c[mt][rr] = 0.f;
+      const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
+      const bool ok = active && b < a.B;
+      const float* p = a.P + (long)(ok ? b : 0) * rowP + u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pre[mt][g][rr] = ok ? p[g * H] : 0.f;
+    }
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
-    // (A) owners: pre-activations of this step (independent of the recurrence -> issued first)
-    float pre[MT][4][4];
-    if (owner) {
+    // (A) next step's pre-activations: independent of the recurrence, in flight under this step
+    float nxt[MT][4][RPW];
+    if (t + 1 < T) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int b = b0 + mt * 16 + q * 4 + r;
-          const bool ok = b < a.B;
-          const float* p = a.P + (long)(ok ? b : 0) * rowP + (long)t * 4 * H + u;
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
+          const bool ok = active && b < a.B;
+          const float* p = a.P + (long)(ok ? b : 0) * rowP + (long)(t + 1) * 4 * H + u;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) pre[mt][g][r] = ok ? p[g * H] : 0.f;
+          for (int g = 0; g < 4; ++g) nxt[mt][g][rr] = ok ? p[g * H] : 0.f;
         }
     }
     // (B) h_{t-1}.W_hh^T on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
@@ -172,83 +191,105 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
             for (int g = 0; g < 4; ++g)
               acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], w[g][kg * 4 + i], acc[mt][g], 0, 0, 0);
         }
-        if (KS > 1 && kp > 0) {
+        if (KS > 1) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + (kp - 1)) * 4 + g) * 64 + lane) * 4) =
-                acc[mt][g];
+            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * KS + kp) * 4 + g) * 64 + lane) * 4) = acc[mt][g];
         }
       }
     }
     __syncthreads();   // all reads of hL done; k-split partials visible
-    // (C) owners: gate math, state update, stores
-    if (owner) {
+    // (C) gate math for this wave's rows, state update, h into LDS and y
+    float st[MT][5][RPW];
+    if (active) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        f32x4 z[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          z[g] = acc[mt][g];
-          if (KS > 1 && t > 0) {
+        for (int rr = 0; rr < RPW; ++rr) {
+          float z[4];
 #pragma unroll
-            for (int p2 = 0; p2 < KS - 1; ++p2) {
-              const f32x4 o = *reinterpret_cast<const f32x4*>(
-                  red + ((((mt * NUG + ug) * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
-              z[g] += o;
+          for (int g = 0; g < 4; ++g) {
+            z[g] = pick_row<KS>(acc[mt][g], kp, rr) + pre[mt][g][rr];
+            if (KS > 1 && t > 0) {
+#pragma unroll
+              for (int p2 = 0; p2 < KS; ++p2)
+                if (p2 != kp) z[g] += red[((((mt * NUG + ug) * KS + p2) * 4 + g) * 64 + lane) * 4 + kp * RPW + rr];
             }
           }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = q * 4 + r;
+          const int row = q * 4 + kp * RPW + rr;
           const int b = b0 + mt * 16 + row;
-          const float ig = tb_sigmoid(z[0][r] + pre[mt][0][r]);
-          const float fg = tb_sigmoid(z[1][r] + pre[mt][1][r]);
-          const float gg = tanhf(z[2][r] + pre[mt][2][r]);
-          const float og = tb_sigmoid(z[3][r] + pre[mt][3][r]);
-          const float cn = fg * c[mt][r] + ig * gg;
-          c[mt][r] = cn;
-          const float hn = og * tanhf(cn);
+          const float ig = fsig(z[0]), fg = fsig(z[1]), gg = ftanh(z[2]), og = fsig(z[3]);
+          const float cn = fg * c[mt][rr] + ig * gg;
+          c[mt][rr] = cn;
+          const float hn = og * ftanh(cn);
+          st[mt][0][rr] = ig; st[mt][1][rr] = fg; st[mt][2][rr] = gg; st[mt][3][rr] = og; st[mt][4][rr] = cn;
           hL[mt * H * 16 + hl_off(row, u)] = hn;
           if (b < a.B) {
             float* yp = a.y + (long)b * rowY + (long)t * H + u;
             if (NCL > 1) tb_store_agent(yp, hn);
             else *yp = hn;
-            if (a.train) {
-              float* p = a.P + (long)b * rowP + (long)t * 4 * H + u;
-              p[0] = ig; p[H] = fg; p[2 * H] = gg; p[3 * H] = og;
-              a.cst[(long)b * rowY + (long)t * H + u] = cn;
-            }
           }
         }
       }
     }
-    if (NCL > 1) {
-      if (t + 1 < T) {
-        // (D) publish this member's h slice, then pull the other members' slices
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
-        if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
-        constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
-        for (int e = tid; e < NV; e += 256) {
-          const int row = e & 15;
-          const int c4 = (e >> 4) % (H / 4);
-          const int mt = e / (16 * (H / 4));
-          const int k = c4 * 4;
-          if (k >= j * US && k < (j + 1) * US) continue;   // own slice already in LDS
-          const int b = b0 + mt * 16 + row;
-          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const bool exchange = NCL > 1 && t + 1 < T;
+    if (exchange) {
+      // publish this member's h slice: drain ONLY the y stores (the stash stores come after the flag)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
+      asm volatile("" ::: "memory");
+    }
+    if (a.train && active) {   // BPTT stash: activated gates over P in place, cell state
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+          const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
           if (b < a.B) {
-            const float* src = a.y + (long)b * rowY + (long)t * H + k;
-            v[0] = tb_load_agent(src); v[1] = tb_load_agent(src + 1);
-            v[2] = tb_load_agent(src + 2); v[3] = tb_load_agent(src + 3);
+            float* p = a.P + (long)b * rowP + (long)t * 4 * H + u;
+            p[0] = st[mt][0][rr]; p[H] = st[mt][1][rr]; p[2 * H] = st[mt][2][rr]; p[3 * H] = st[mt][3][rr];
+            a.cst[(long)b * rowY + (long)t * H + u] = st[mt][4][rr];
           }
-          *reinterpret_cast<f32x4*>(hL + mt * H * 16 + hl_off(row, k)) = v;
         }
+    }
+    if (exchange) {
+      if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
+      // pull the other members' slices (write-through stored) with L1-bypassing 16-byte loads
+      int vrows = a.B - b0;
+      if (vrows > 16 * MT) vrows = 16 * MT;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.y + (long)b0 * rowY), 0, (int)((long)vrows * rowY * 4), 0x00020000);
+      constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
+      constexpr int NLD = (NV + 255) / 256;
+      u32x4 buf[NLD];
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const int e = tid + 256 * n;
+        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
+        const bool mine = (c4 * 4) / US == j;
+        buf[n] = (u32x4){0u, 0u, 0u, 0u};
+        if (e < NV && !mine)
+          buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, 16);
+      }
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const int e = tid + 256 * n;
+        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
+        const bool mine = (c4 * 4) / US == j;
+        if (e < NV && !mine)
+          *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
       }
     }
     __syncthreads();   // hL complete for step t+1
+    if (t + 1 < T) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int rr = 0; rr < RPW; ++rr) pre[mt][g][rr] = nxt[mt][g][rr];
+    }
   }
 }
 
@@ -258,7 +299,7 @@ struct BwdArgs {
   const float* cst;    // [B][T][H]
   const float* dy;     // [B][T][H]
   const float* Whh;    // [4H][H]
-  float* X;            // [nclusters][2][NCL][MT*16][H] exchange slabs (NCL > 1)
+  float* X;            // [nclusters][2][MT*16][H][NCL] exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
   unsigned* flags;
   int* err;
@@ -278,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
   constexpr int NI = MT * 16 * US / 256;           // (row,unit) items per thread
   constexpr int LDH = H + 4;                       // dhL row stride (floats)
-  static_assert(NI >= 1 && (256 % US) == 0, "bad config");
+  static_assert(NI >= 1 && (256 % US) == 0 && (NCL == 1 || NCL % 4 == 0), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgL = smem;                               // [MT][KD/16][64][4]
@@ -294,7 +335,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
   unsigned* flags = a.flags + cl * NCL;
-  float* Xc = a.X + (size_t)cl * 2 * NCL * MT * 16 * H;
+  // exchange slab of this cluster: [parity][MT*16 rows][H cols][NCL members] (member fastest, so the
+  // reduce-scatter reads NCL contiguous floats per (row, unit))
+  float* Xc = a.X + (size_t)cl * 2 * MT * 16 * H * NCL;
   if (tid == 0) *s_dead = 0;
 
   // W_hh fragments: B[k][n] = W_hh[grow(k)][n], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
@@ -314,96 +357,151 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int ul = tid % US;
   const int uabs = j * US + ul;
   float dc[NI], dhrec[NI], dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  // stash of the current step (prefetched one step ahead): i, f, g, o, c_t, c_{t-1}, dy
+  float cur[NI][7];
 #pragma unroll
-  for (int n = 0; n < NI; ++n) { dc[n] = 0.f; dhrec[n] = 0.f; }
+  for (int n = 0; n < NI; ++n) {
+    dc[n] = 0.f; dhrec[n] = 0.f;
+    const int e = tid + 256 * n;
+    const int row = (e / US) & 15, mt = e / (16 * US);
+    const int b = b0 + mt * 16 + row;
+    const bool ok = b < a.B;
+    const long bb = ok ? b : 0;
+    const float* gp = a.G + bb * rowG + (long)(T - 1) * 4 * H + uabs;
+    cur[n][0] = ok ? gp[0] : 0.f; cur[n][1] = ok ? gp[H] : 0.f;
+    cur[n][2] = ok ? gp[2 * H] : 0.f; cur[n][3] = ok ? gp[3 * H] : 0.f;
+    cur[n][4] = ok ? a.cst[bb * rowY + (long)(T - 1) * H + uabs] : 0.f;
+    cur[n][5] = (ok && T > 1) ? a.cst[bb * rowY + (long)(T - 2) * H + uabs] : 0.f;
+    cur[n][6] = ok ? a.dy[bb * rowY + (long)(T - 1) * H + uabs] : 0.f;
+  }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
+    // prefetch step t-1 (its c_t is this step's c_{t-1}, already held)
+    float nx[NI][6];
+    if (t > 0) {
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int e = tid + 256 * n;
+        const int row = (e / US) & 15, mt = e / (16 * US);
+        const int b = b0 + mt * 16 + row;
+        const bool ok = b < a.B;
+        const long bb = ok ? b : 0;
+        const float* gp = a.G + bb * rowG + (long)(t - 1) * 4 * H + uabs;
+        nx[n][0] = ok ? gp[0] : 0.f; nx[n][1] = ok ? gp[H] : 0.f;
+        nx[n][2] = ok ? gp[2 * H] : 0.f; nx[n][3] = ok ? gp[3 * H] : 0.f;
+        nx[n][4] = (ok && t > 1) ? a.cst[bb * rowY + (long)(t - 2) * H + uabs] : 0.f;
+        nx[n][5] = ok ? a.dy[bb * rowY + (long)(t - 1) * H + uabs] : 0.f;
+      }
+    }
     // (A) gate gradients for this member's units
+    float dgv[NI][4];
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int e = tid + 256 * n;
       const int row = (e / US) & 15, mt = e / (16 * US);
-      const int b = b0 + mt * 16 + row;
-      float di = 0.f, df = 0.f, dg = 0.f, dob = 0.f;
-      if (b < a.B) {
-        float* gp = a.G + (long)b * rowG + (long)t * 4 * H + uabs;
-        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-        const float ct = a.cst[(long)b * rowY + (long)t * H + uabs];
-        const float cprev = t > 0 ? a.cst[(long)b * rowY + (long)(t - 1) * H + uabs] : 0.f;
-        const float dh = a.dy[(long)b * rowY + (long)t * H + uabs] + dhrec[n];
-        const float tc = tanhf(ct);
-        const float dcn = dc[n] + dh * og * (1.f - tc * tc);
-        dob = dh * tc * og * (1.f - og);
-        di = dcn * gg * ig * (1.f - ig);
-        dg = dcn * ig * (1.f - gg * gg);
-        df = dcn * cprev * fg * (1.f - fg);
-        dc[n] = dcn * fg;
-        gp[0] = di; gp[H] = df; gp[2 * H] = dg; gp[3 * H] = dob;
-        dbacc[0] += di; dbacc[1] += df; dbacc[2] += dg; dbacc[3] += dob;
-      }
+      const float ig = cur[n][0], fg = cur[n][1], gg = cur[n][2], og = cur[n][3];
+      const float dh = cur[n][6] + dhrec[n];
+      const float tc = ftanh(cur[n][4]);
+      const float dcn = dc[n] + dh * og * (1.f - tc * tc);
+      const float dob = dh * tc * og * (1.f - og);
+      const float di = dcn * gg * ig * (1.f - ig);
+      const float dg = dcn * ig * (1.f - gg * gg);
+      const float df = dcn * cur[n][5] * fg * (1.f - fg);
+      dc[n] = dcn * fg;
+      dgv[n][0] = di; dgv[n][1] = df; dgv[n][2] = dg; dgv[n][3] = dob;
+      dbacc[0] += di; dbacc[1] += df; dbacc[2] += dg; dbacc[3] += dob;
       float* dl = dgL + mt * KD * 16;
       dl[hl_off(row, ul)] = di;
       dl[hl_off(row, US + ul)] = df;
       dl[hl_off(row, 2 * US + ul)] = dg;
       dl[hl_off(row, 3 * US + ul)] = dob;
     }
-    if (t == 0) break;     // dh_{-1} is never used
-    __syncthreads();
-    // (B) partial dh_{t-1} = dgates_t . W_hh[rows of this member]
+    const bool last = t == 0;           // dh_{-1} is never used
     const int par = t & 1;
-    if (mactive) {
+    if (!last) {
+      __syncthreads();
+      // (B) partial dh_{t-1} = dgates_t . W_hh[rows of this member]
+      if (mactive) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 acc[NTW];
+        for (int mt = 0; mt < MT; ++mt) {
+          f32x4 acc[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kg = 0; kg < KGD; ++kg) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
+          for (int kg = 0; kg < KGD; ++kg) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wb[nt][kg * 4 + i], acc[nt], 0, 0, 0);
-        }
+              for (int nt = 0; nt < NTW; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wb[nt][kg * 4 + i], acc[nt], 0, 0, 0);
+          }
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          const int ncol = (wave * NTW + nt) * 16 + col;
-          const bool own = (ncol / US) == j;
+          for (int nt = 0; nt < NTW; ++nt) {
+            const int ncol = (wave * NTW + nt) * 16 + col;
+            const bool own = (ncol / US) == j;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = q * 4 + r;
-            if (NCL == 1 || own) dhL[(mt * 16 + row) * LDH + ncol] = acc[nt][r];
-            else tb_store_agent(Xc + ((size_t)(par * NCL + j) * MT * 16 + mt * 16 + row) * H + ncol, acc[nt][r]);
+            for (int r = 0; r < 4; ++r) {
+              const int row = q * 4 + r;
+              if (NCL == 1 || own) dhL[(mt * 16 + row) * LDH + ncol] = acc[nt][r];
+              else tb_store_agent(Xc + (((size_t)par * MT * 16 + mt * 16 + row) * H + ncol) * NCL + j, acc[nt][r]);
+            }
           }
         }
       }
+      if (NCL > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(T - t));
+        asm volatile("" ::: "memory");
+      } else {
+        __syncthreads();
+      }
     }
-    if (NCL > 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      const unsigned step = (unsigned)(T - t);      // 1, 2, ... monotonic
-      if (tid == 0) tb_store_agent_u32(flags + j, step);
-      if (!wait_members(flags, NCL, j, step, a.timeout_ticks, a.err, s_dead)) break;
-    } else {
-      __syncthreads();
-    }
-    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials
+    // dgates of this step over the gate stash, in place (after the publish: not on its critical path)
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int e = tid + 256 * n;
       const int row = (e / US) & 15, mt = e / (16 * US);
-      float s = dhL[(mt * 16 + row) * LDH + uabs];
-      if (NCL > 1) {
-        for (int m = 0; m < NCL; ++m) {
-          if (m == j) continue;
-          s += tb_load_agent(Xc + ((size_t)(par * NCL + m) * MT * 16 + mt * 16 + row) * H + uabs);
-        }
+      const int b = b0 + mt * 16 + row;
+      if (b < a.B) {
+        float* gp = a.G + (long)b * rowG + (long)t * 4 * H + uabs;
+        gp[0] = dgv[n][0]; gp[H] = dgv[n][1]; gp[2 * H] = dgv[n][2]; gp[3 * H] = dgv[n][3];
       }
-      dhrec[n] = s;
+    }
+    if (last) break;
+    if (NCL > 1 && !wait_members(flags, NCL, j, (unsigned)(T - t), a.timeout_ticks, a.err, s_dead)) break;
+    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials
+    {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)Xc, 0, (int)((size_t)2 * MT * 16 * H * NCL * 4), 0x00020000);
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int e = tid + 256 * n;
+        const int row = (e / US) & 15, mt = e / (16 * US);
+        float s = dhL[(mt * 16 + row) * LDH + uabs];
+        if (NCL > 1) {
+          const int base = (int)(((((size_t)par * MT * 16 + mt * 16 + row) * H + uabs) * NCL) * 4);
+#pragma unroll
+          for (int m4 = 0; m4 < NCL / 4; ++m4) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + m4 * 16, 0, 16);
+            const f32x4 f = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (m4 * 4 + i != j) s += f[i];
+          }
+        }
+        dhrec[n] = s;
+      }
     }
     __syncthreads();   // dhL / dgL free for the next step
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      cur[n][4] = cur[n][5];
+      cur[n][0] = nx[n][0]; cur[n][1] = nx[n][1]; cur[n][2] = nx[n][2]; cur[n][3] = nx[n][3];
+      cur[n][5] = nx[n][4]; cur[n][6] = nx[n][5];
+    }
   }
   // bias grads of this cluster: reduce the threads that share a unit, one partial row per cluster
   __syncthreads();
@@ -459,13 +557,13 @@ bool make_plan(int H, int B, Plan& p) {
   const int cus = tb_num_cus();
   const int max_clusters = cus / p.NCL > 0 ? cus / p.NCL : 1;
   int MT = 1;
-  const int mt_cap = (H >= 512) ? 1 : (H >= 256 ? 2 : 4);
+  const int mt_cap = (H >= 512) ? 1 : ((H >= 256 || H == 64) ? 2 : 4);
   while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters) MT *= 2;
   p.MT = MT;
   p.rows_per_cluster = 16 * MT;
   p.clusters_per_launch = max_clusters;
   const int NUG = US / 16;
-  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
+  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS > 1 ? KS : 0) * NUG * MT * 4 * 256) * 4 + 16;
   p.lds_bwd = ((size_t)MT * 4 * US * 16 + (size_t)MT * 16 * (H + 4) + 1024) * 4 + 16;
   return true;
 }
@@ -504,7 +602,7 @@ int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
 int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(16, 16, 1, 1); FWD_CASE(16, 16, 1, 2); FWD_CASE(16, 16, 1, 4);
   FWD_CASE(32, 32, 2, 1); FWD_CASE(32, 32, 2, 2); FWD_CASE(32, 32, 2, 4);
-  FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2); FWD_CASE(64, 64, 1, 4);
+  FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   FWD_CASE(256, 32, 2, 1); FWD_CASE(256, 32, 2, 2);
   FWD_CASE(512, 16, 4, 1);
@@ -514,7 +612,7 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
 int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
   BWD_CASE(16, 16, 1); BWD_CASE(16, 16, 2); BWD_CASE(16, 16, 4);
   BWD_CASE(32, 32, 1); BWD_CASE(32, 32, 2); BWD_CASE(32, 32, 4);
-  BWD_CASE(64, 64, 1); BWD_CASE(64, 64, 2); BWD_CASE(64, 64, 4);
+  BWD_CASE(64, 64, 1); BWD_CASE(64, 64, 2);
   BWD_CASE(128, 32, 1); BWD_CASE(128, 32, 2); BWD_CASE(128, 32, 4);
   BWD_CASE(256, 32, 1); BWD_CASE(256, 32, 2);
   BWD_CASE(512, 16, 1);
