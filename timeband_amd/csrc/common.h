@@ -46,6 +46,9 @@ __device__ __forceinline__ float tb_load_agent(const float* p) {
 __device__ __forceinline__ void tb_store_agent_u32(unsigned* p, unsigned v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void tb_store_agent_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ unsigned tb_load_agent_u32(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

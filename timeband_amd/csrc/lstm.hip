@@ -36,7 +36,6 @@ struct FwdArgs {
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
-  unsigned* flags;     // [nclusters][NCL] step counters, zeroed before launch
   int* err;            // [4] sticky error words
   int B, T;
   int b_begin;         // first batch row of this launch
@@ -66,31 +65,7 @@ __device__ __forceinline__ void cluster_decode(int ncl, int NCL, int& cl, int& j
   (void)ncl;
 }
 
-// Wait until every other member's counter reaches `target`.  Returns false on timeout.
-__device__ __forceinline__ bool wait_members(const unsigned* flags, int NCL, int j, unsigned target,
-                                             unsigned long long timeout, int* err, int* s_dead) {
-  const int lane = threadIdx.x & 63;
-  if (threadIdx.x < 64) {
-    bool ok = true;
-    if (lane < NCL && lane != j) {
-      const unsigned long long t0 = wall_clock64();
-      unsigned it = 0;
-      while (tb_load_agent_u32(flags + lane) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++it & 1023u) == 0 && wall_clock64() - t0 > timeout) {
-          ok = false;
-          break;
-        }
-      }
-    }
-    if (!ok) {
-      atomicExch(err, 1);
-      *s_dead = 1;
-    }
-  }
-  __syncthreads();
-  return *s_dead == 0;
-}
+constexpr unsigned kSentinel = 0xFFFFFFFFu;   // all-ones: a NaN pattern no finite h equals
 
 __device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
@@ -129,7 +104,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
-  unsigned* flags = a.flags + cl * NCL;
   if (tid == 0) *s_dead = 0;
 
   // W_hh fragments: B[k][n] = W_hh[g*H + u][k]; MFMA step (kg,i) uses k = kp*KPER + kg*16 + q*4 + i
@@ -234,13 +208,58 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     }
     const bool exchange = NCL > 1 && t + 1 < T;
     if (exchange) {
-      // publish this member's h slice: drain ONLY the y stores (the stash stores come after the flag)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
-      asm volatile("" ::: "memory");
+      // Pull the other members' slices of h_t.  y was armed with the sentinel (all-ones, a NaN no
+      // finite h can equal) before the launch and every (b,t,u) is written exactly once, so the data
+      // is its own ready flag: poll with L1-bypassing 16-byte loads until no dword is the sentinel.
+      int vrows = a.B - b0;
+      if (vrows > 16 * MT) vrows = 16 * MT;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(a.y + (long)b0 * rowY), 0, (int)((long)vrows * rowY * 4), 0x00020000);
+      constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
+      constexpr int NLD = (NV + 255) / 256;
+      u32x4 buf[NLD];
+      unsigned pend = 0;
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const int e = tid + 256 * n;
+        const int c4 = (e >> 4) % (H / 4);
+        if (e < NV && (c4 * 4) / US != j) pend |= 1u << n;
+      }
+      const unsigned want = pend;
+      unsigned it = 0;
+      unsigned long long t0 = 0;
+      while (pend) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+          const int e = tid + 256 * n;
+          const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
+          if ((pend >> n) & 1u)
+            buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, 16);
+        }
+#pragma unroll
+        for (int n = 0; n < NLD; ++n)
+          if (((pend >> n) & 1u) && buf[n][0] != kSentinel && buf[n][1] != kSentinel && buf[n][2] != kSentinel &&
+              buf[n][3] != kSentinel)
+            pend &= ~(1u << n);
+        if (pend && (++it & 255u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > a.timeout_ticks) {
+            atomicExch(a.err, 1);
+            *s_dead = 1;
+            break;
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const int e = tid + 256 * n;
+        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
+        if ((want >> n) & 1u) *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
+      }
     }
-    if (a.train && active) {   // BPTT stash: activated gates over P in place, cell state
+    if (a.train && active) {   // BPTT stash (off the critical path): activated gates over P in place, cell state
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -253,35 +272,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           }
         }
     }
-    if (exchange) {
-      if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
-      // pull the other members' slices (write-through stored) with L1-bypassing 16-byte loads
-      int vrows = a.B - b0;
-      if (vrows > 16 * MT) vrows = 16 * MT;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.y + (long)b0 * rowY), 0, (int)((long)vrows * rowY * 4), 0x00020000);
-      constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
-      constexpr int NLD = (NV + 255) / 256;
-      u32x4 buf[NLD];
-#pragma unroll
-      for (int n = 0; n < NLD; ++n) {
-        const int e = tid + 256 * n;
-        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-        const bool mine = (c4 * 4) / US == j;
-        buf[n] = (u32x4){0u, 0u, 0u, 0u};
-        if (e < NV && !mine)
-          buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, 16);
-      }
-#pragma unroll
-      for (int n = 0; n < NLD; ++n) {
-        const int e = tid + 256 * n;
-        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-        const bool mine = (c4 * 4) / US == j;
-        if (e < NV && !mine)
-          *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
-      }
-    }
     __syncthreads();   // hL complete for step t+1
+    if (NCL > 1 && *s_dead) break;   // a member timed out (uniform: read after the barrier)
     if (t + 1 < T) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -299,9 +291,8 @@ struct BwdArgs {
   const float* cst;    // [B][T][H]
   const float* dy;     // [B][T][H]
   const float* Whh;    // [4H][H]
-  float* X;            // [nclusters][2][MT*16][H][NCL] exchange slabs (NCL > 1)
+  unsigned long long* X;   // [nclusters][2][MT*16][H][NCL] (value, tag) exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
-  unsigned* flags;
   int* err;
   int B, T;
   int b_begin;
@@ -319,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
   constexpr int NI = MT * 16 * US / 256;           // (row,unit) items per thread
   constexpr int LDH = H + 4;                       // dhL row stride (floats)
-  static_assert(NI >= 1 && (256 % US) == 0 && (NCL == 1 || NCL % 4 == 0), "bad config");
+  static_assert(NI >= 1 && (256 % US) == 0 && (NCL == 1 || NCL % 2 == 0) && NI * (NCL > 1 ? NCL / 2 : 1) <= 32, "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgL = smem;                               // [MT][KD/16][64][4]
@@ -334,10 +325,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
-  unsigned* flags = a.flags + cl * NCL;
   // exchange slab of this cluster: [parity][MT*16 rows][H cols][NCL members] (member fastest, so the
   // reduce-scatter reads NCL contiguous floats per (row, unit))
-  float* Xc = a.X + (size_t)cl * 2 * MT * 16 * H * NCL;
+  unsigned long long* Xc = a.X + (size_t)cl * 2 * MT * 16 * H * NCL;
   if (tid == 0) *s_dead = 0;
 
   // W_hh fragments: B[k][n] = W_hh[grow(k)][n], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
@@ -419,6 +409,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     }
     const bool last = t == 0;           // dh_{-1} is never used
     const int par = t & 1;
+    const unsigned tag = (unsigned)(T - t);
     if (!last) {
       __syncthreads();
       // (B) partial dh_{t-1} = dgates_t . W_hh[rows of this member]
@@ -445,19 +436,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             for (int r = 0; r < 4; ++r) {
               const int row = q * 4 + r;
               if (NCL == 1 || own) dhL[(mt * 16 + row) * LDH + ncol] = acc[nt][r];
-              else tb_store_agent(Xc + (((size_t)par * MT * 16 + mt * 16 + row) * H + ncol) * NCL + j, acc[nt][r]);
+              else   // (value, step tag) in one 8-byte write-through store: the pair is its own ready flag
+                tb_store_agent_u64(Xc + (((size_t)par * MT * 16 + mt * 16 + row) * H + ncol) * NCL + j,
+                                   ((unsigned long long)tag << 32) | __float_as_uint(acc[nt][r]));
             }
           }
         }
       }
-      if (NCL > 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(T - t));
-        asm volatile("" ::: "memory");
-      } else {
-        __syncthreads();
-      }
+      __syncthreads();   // own columns of dhL visible
     }
     // dgates of this step over the gate stash, in place (after the publish: not on its critical path)
 #pragma unroll
@@ -471,31 +457,69 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       }
     }
     if (last) break;
-    if (NCL > 1 && !wait_members(flags, NCL, j, (unsigned)(T - t), a.timeout_ticks, a.err, s_dead)) break;
-    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials
+    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials.
+    // Every slab slot is an 8-byte (value, tag) pair written by one store, so it is its own ready
+    // flag (no store drain, no separate flag round trip): poll with L1-bypassing 16-byte loads (two
+    // pairs each) until every foreign tag equals this step's.  The slab is zeroed before the launch
+    // and tags start at 1.  Two parities: a slot is rewritten two steps later, and its writer gets
+    // there only after consuming this member's partial of the step in between, which this member
+    // produces after it has finished reading here.
     {
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)Xc, 0, (int)((size_t)2 * MT * 16 * H * NCL * 4), 0x00020000);
+          (void*)Xc, 0, (int)((size_t)2 * MT * 16 * H * NCL * 8), 0x00020000);
+      constexpr int NQ = NCL > 1 ? NCL / 2 : 1;
+      u32x4 buf[NI][NQ];
+      unsigned pend = NCL > 1 ? (1u << (NI * NQ)) - 1u : 0u;
+      unsigned it = 0;
+      unsigned long long t0 = 0;
+      while (pend) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+          const int e = tid + 256 * n;
+          const int row = (e / US) & 15, mt = e / (16 * US);
+          const int base = (int)(((((size_t)par * MT * 16 + mt * 16 + row) * H + uabs) * NCL) * 8);
+#pragma unroll
+          for (int m2 = 0; m2 < NQ; ++m2)
+            if ((pend >> (n * NQ + m2)) & 1u) buf[n][m2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + m2 * 16, 0, 16);
+        }
+#pragma unroll
+        for (int n = 0; n < NI; ++n)
+#pragma unroll
+          for (int m2 = 0; m2 < NQ; ++m2) {
+            const bool ready = (m2 * 2 == j || buf[n][m2][1] == tag) && (m2 * 2 + 1 == j || buf[n][m2][3] == tag);
+            if (ready) pend &= ~(1u << (n * NQ + m2));
+          }
+        if (pend && (++it & 255u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > a.timeout_ticks) {
+            atomicExch(a.err, 1);
+            *s_dead = 1;
+            break;
+          }
+        }
+      }
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
         const int e = tid + 256 * n;
         const int row = (e / US) & 15, mt = e / (16 * US);
         float s = dhL[(mt * 16 + row) * LDH + uabs];
         if (NCL > 1) {
-          const int base = (int)(((((size_t)par * MT * 16 + mt * 16 + row) * H + uabs) * NCL) * 4);
 #pragma unroll
-          for (int m4 = 0; m4 < NCL / 4; ++m4) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + m4 * 16, 0, 16);
-            const f32x4 f = __builtin_bit_cast(f32x4, v);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (m4 * 4 + i != j) s += f[i];
+          for (int m2 = 0; m2 < NQ; ++m2) {
+            if (m2 * 2 != j) s += __uint_as_float(buf[n][m2][0]);
+            if (m2 * 2 + 1 != j) s += __uint_as_float(buf[n][m2][2]);
           }
         }
         dhrec[n] = s;
       }
     }
-    __syncthreads();   // dhL / dgL free for the next step
+    if (NCL > 1) {
+      // a timed-out member must stop the whole workgroup: make the verdict uniform
+      __syncthreads();
+      if (*s_dead) break;
+    }
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       cur[n][4] = cur[n][5];
@@ -621,36 +645,30 @@ int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
 
 constexpr unsigned long long kTimeoutTicks = 200000000ull;   // 2 s of the 100 MHz realtime counter
 
-// workspace carve: [flags | bias sum | dbpart | X | gemm split-k slabs]
+// workspace carve: [bias sum | dbpart | X | gemm split-k slabs]
 struct Carve {
-  unsigned* flags; size_t flags_bytes;
   float* bsum;
   float* dbpart;
-  float* X;
+  unsigned long long* X; size_t x_bytes;
   float* gemm_ws; size_t gemm_ws_bytes;
 };
 
 size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   size_t off = 0;
-  const size_t flags_bytes = tb_align_up((size_t)ncl_total * p.NCL * sizeof(unsigned), 256);
   const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
   const size_t x_bytes = (bwd && p.NCL > 1)
-                             ? tb_align_up((size_t)ncl_launch * 2 * p.NCL * p.rows_per_cluster * H * sizeof(float), 256)
+                             ? tb_align_up((size_t)ncl_launch * 2 * p.NCL * p.rows_per_cluster * H * sizeof(unsigned long long), 256)
                              : 0;
   const int widest = in_dim > H ? in_dim : H;
   const size_t gemm_bytes = bwd ? tb_align_up((size_t)64 * 4 * H * widest * sizeof(float), 256) : 0;
-  if (c) {
-    c->flags = reinterpret_cast<unsigned*>(base + off); c->flags_bytes = flags_bytes;
-  }
-  off += flags_bytes;
   if (c) c->bsum = reinterpret_cast<float*>(base + off);
   off += bsum_bytes;
   if (c) c->dbpart = reinterpret_cast<float*>(base + off);
   off += dbpart_bytes;
-  if (c) c->X = reinterpret_cast<float*>(base + off);
+  if (c) { c->X = reinterpret_cast<unsigned long long*>(base + off); c->x_bytes = x_bytes; }
   off += x_bytes;
   if (c) {
     c->gemm_ws = reinterpret_cast<float*>(base + off);
@@ -689,7 +707,8 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   Carve c;
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
-  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
+  // arm y with the sentinel the cluster members poll on (see lstm_fwd_kernel)
+  if (p.NCL > 1) TB_HIP(hipMemsetAsync(y, 0xFF, (size_t)B * T * H * sizeof(float), s));
   // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash
   const float* bias = nullptr;
   if (b_ih && b_hh) {
@@ -707,7 +726,6 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     FwdArgs a;
     a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
-    a.flags = c.flags + (size_t)c0 * p.NCL;
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
@@ -735,7 +753,6 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   Carve c;
   const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
-  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   int rc;
   // algorithmic bytes of one layer backward: read 5h stash + dy, read x, write dx
@@ -746,11 +763,11 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     a.G = gates; a.cst = cstash; a.dy = dy; a.Whh = w_hh;
     a.X = c.X;
     a.dbpart = c.dbpart;
-    a.flags = c.flags + (size_t)c0 * p.NCL;
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.cl_begin = c0;
+    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.X, 0, c.x_bytes, s));   // tags start below 1
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
     rc = launch_bwd(p, a, ncl * p.NCL, s);
