@@ -15,15 +15,20 @@
 // Persistent kernel layout.  The batch is cut into tiles of 16*MT rows; a CLUSTER of NCL = H/US
 // workgroups (one per CU, all co-resident: grid <= #CUs) owns one tile.  Member j owns hidden
 // units [j*US, (j+1)*US): in forward the 4*US rows of W_hh that produce its gates, held in
-// VGPRs for the whole sequence as MFMA B-operand fragments (W_hh never leaves the register file
-// between timesteps); c stays in registers too.  Each timestep every member needs the whole
-// h_{t-1} tile: members write their h slice to y[b,t,:] with write-through (sc1) stores, raise a
-// per-member step counter, poll the other members' counters (bounded spin) and read the other
-// slices with L1-bypassing (sc1) loads -- the Guideline-16 protocol of cdna_hip_programming.md.
-// In backward the same W_hh rows are the B operand of dh_{t-1} = dgates_t.W_hh; the per-member
-// partial sums over gate rows are exchanged reduce-scatter style through a double-buffered slab.
-// NCL == 1 (H <= 64) needs no global exchange at all.
+// VGPRs for the whole sequence as MFMA A-operand fragments (W_hh never leaves the register file
+// between timesteps); c stays in registers too.  The products are computed TRANSPOSED
+// (gates^T = W_hh . h^T), so a lane's four accumulator registers are four consecutive hidden
+// units of one batch row: every global access of the step (pre-activations, stash, y, the
+// exchange) is a 16-byte access, and the write-through (sc1) exchange stores -- one fabric write
+// each whatever their width -- are 4x fewer than with 4-byte stores.
+// Each timestep every member needs the whole h_{t-1} tile: members write their h slice to
+// y[b,t,:] with sc1 stores, raise a per-member step counter, poll the other members' counters
+// (bounded spin) and read the other slices with L1-bypassing (sc1) loads -- the Guideline-16
+// protocol of cdna_hip_programming.md.  In backward the same W_hh rows produce this member's
+// partial of dh_{t-1} = dgates_t.W_hh; the partials are exchanged reduce-scatter style through a
+// double-buffered slab.  NCL == 1 (H <= 64) needs no global exchange at all.
 #include "common.h"
+#include <stdlib.h>
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
@@ -31,28 +36,34 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
 
 namespace {
 
+constexpr unsigned kSentinel = 0xFFFFFFFFu;   // all-ones: a NaN pattern no computed h equals
+constexpr int kBufFlags = 0x00020000;         // raw buffer descriptor word 3 (32-bit raw, bounds-checked)
+constexpr int kSC1 = 16;                      // aux: sc1 = write-through store / L1-bypassing load
+
 struct FwdArgs {
   float* P;            // [B][T][4H] in: pre-activations from the projection; out: activated gates
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
+  unsigned* flags;     // [nclusters][NCL] step counters, zeroed before launch
   int* err;            // [4] sticky error words
   int B, T;
   int b_begin;         // first batch row of this launch
   int nclusters;
   int train;
+  int mode;            // bit 0: y is sentinel-armed and is its own ready flag (no drain, no counter)
   unsigned long long timeout_ticks;
 };
 
 __device__ __forceinline__ int hl_off(int row, int k) {
-  // LDS image of a [16][K] tile laid out so that one ds_read_b128 per lane yields the MFMA A
+  // LDS image of a [16][K] tile laid out so that one ds_read_b128 per lane yields the MFMA
   // operand of 4 consecutive k-steps: float offset of element (row, k).
   return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + row) << 2) + (k & 3);
 }
 
 // cluster/member decode: keep the members of a cluster on blocks with equal (blockIdx % 8), i.e.
 // on one XCD under the observed round-robin placement (speed only; correctness never depends on it)
-__device__ __forceinline__ void cluster_decode(int ncl, int NCL, int& cl, int& j) {
+__device__ __forceinline__ void cluster_decode(int NCL, int& cl, int& j) {
   const int G = gridDim.x, b = blockIdx.x;
   if ((G & 7) == 0 && ((G >> 3) % NCL) == 0) {
     const int x = b & 7, slot = b >> 3, per = (G >> 3) / NCL;
@@ -62,20 +73,44 @@ __device__ __forceinline__ void cluster_decode(int ncl, int NCL, int& cl, int& j
     cl = b / NCL;
     j = b % NCL;
   }
-  (void)ncl;
 }
 
-constexpr unsigned kSentinel = 0xFFFFFFFFu;   // all-ones: a NaN pattern no finite h equals
+// Wait until every other member's counter reaches `target`.  Returns false on timeout.
+__device__ __forceinline__ bool wait_members(const unsigned* flags, int NCL, int j, unsigned target,
+                                             unsigned long long timeout, int* err, int* s_dead) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+    bool ok = true;
+    if (lane < NCL && lane != j) {
+      const unsigned long long t0 = wall_clock64();
+      unsigned it = 0;
+      while (tb_load_agent_u32(flags + lane) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++it & 1023u) == 0 && wall_clock64() - t0 > timeout) {
+          ok = false;
+          break;
+        }
+      }
+    }
+    if (!ok) {
+      atomicExch(err, 1);
+      *s_dead = 1;
+    }
+  }
+  __syncthreads();
+  return *s_dead == 0;
+}
 
 __device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
-// element r0+rr of a 4-row accumulator, r0 = kp*RPW, without dynamic register indexing
-template <int KS>
-__device__ __forceinline__ float pick_row(const f32x4& v, int kp, int rr) {
-  if (KS == 1) return v[rr];
-  if (KS == 2) return kp ? v[2 + rr] : v[rr];
-  return kp == 0 ? v[0] : (kp == 1 ? v[1] : (kp == 2 ? v[2] : v[3]));
+template <int AUX>
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, long float_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void stg4(__amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(float_off * 4), 0, AUX);
 }
 
 template <int H, int US, int KS, int MT>
@@ -84,70 +119,69 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NCL = H / US;           // members per cluster
   constexpr int KPER = H / KS;          // k range per wave
   constexpr int KG = KPER / 16;         // 16-wide k groups per wave
-  constexpr int NACT = NUG * KS;        // waves doing work
-  constexpr int RPW = 4 / KS;           // accumulator rows each k-split partner finishes
-  constexpr int RED = KS > 1 ? KS * NUG * MT * 4 * 256 : 0;   // floats of k-split scratch
-  static_assert(NACT <= 4 && KPER % 16 == 0 && H % US == 0, "bad config");
+  constexpr int NACT = NUG * KS;        // waves doing MFMA work
+  constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
+  constexpr int NV = MT * 16 * (H / 4); // 16-byte pieces of the whole h tile
+  constexpr int NLD = (NV + 255) / 256;
+  static_assert(NACT <= 4 && KPER % 16 == 0 && H % US == 0 && (NCL == 1 || NV % 256 == 0), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* hL = smem;                                    // [MT][H/16][64][4]
-  float* red = smem + MT * H * 16;                     // [MT][NUG][KS][4][64][4]
+  float* red = smem + MT * H * 16;                     // [MT][NUG][KS-1][4][64][4]
   int* s_dead = reinterpret_cast<int*>(smem + MT * H * 16 + RED);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
   int cl, j;
-  cluster_decode(a.nclusters, NCL, cl, j);
+  cluster_decode(NCL, cl, j);
   const bool active = wave < NACT;
   const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
-  const int u = j * US + ug * 16 + col;                // hidden unit of this lane
+  const bool fin = active && kp == 0;                  // this wave finishes the gates of its unit group
+  const int uw = j * US + ug * 16 + col;               // W_hh row (per gate) this lane feeds to the MFMA
+  const int u0 = j * US + ug * 16 + q * 4;             // first of the 4 hidden units this lane finishes
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
+  unsigned* flags = a.flags + cl * NCL;
   if (tid == 0) *s_dead = 0;
+  // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
+  int vrows = a.B - b0;
+  if (vrows > 16 * MT) vrows = 16 * MT;
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (long)b0 * rowP), 0, (int)(vrows * rowP * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
 
-  // W_hh fragments: B[k][n] = W_hh[g*H + u][k]; MFMA step (kg,i) uses k = kp*KPER + kg*16 + q*4 + i
+  // W_hh fragments (A operand): A[m][k] = W_hh[g*H + uw][k]; MFMA step (kg,i) uses k = kp*KPER + kg*16 + q*4 + i
   float w[4][KG * 4];
   if (active) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int kg = 0; kg < KG; ++kg) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + u) * H + kp * KPER + kg * 16 + q * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + uw) * H + kp * KPER + kg * 16 + q * 4);
         w[g][kg * 4 + 0] = v[0]; w[g][kg * 4 + 1] = v[1]; w[g][kg * 4 + 2] = v[2]; w[g][kg * 4 + 3] = v[3];
       }
   }
-  // this wave finishes accumulator rows [kp*RPW, kp*RPW+RPW) of every 4-row group
-  float c[MT][RPW], pre[MT][4][RPW];
+  f32x4 c[MT], pre[MT][4];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
+    c[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      c[mt][rr] = 0.f;
-      const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
-      const bool ok = active && b < a.B;
-      const float* p = a.P + (long)(ok ? b : 0) * rowP + u;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) pre[mt][g][rr] = ok ? p[g * H] : 0.f;
-    }
+    for (int g = 0; g < 4; ++g)
+      pre[mt][g] = fin ? ldg4<0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   __syncthreads();
 
   for (int t = 0; t < T; ++t) {
     // (A) next step's pre-activations: independent of the recurrence, in flight under this step
-    float nxt[MT][4][RPW];
-    if (t + 1 < T) {
+    f32x4 nxt[MT][4];
+    if (t + 1 < T && fin) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-          const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
-          const bool ok = active && b < a.B;
-          const float* p = a.P + (long)(ok ? b : 0) * rowP + (long)(t + 1) * 4 * H + u;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) nxt[mt][g][rr] = ok ? p[g * H] : 0.f;
-        }
+        for (int g = 0; g < 4; ++g) nxt[mt][g] = ldg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
     }
-    // (B) h_{t-1}.W_hh^T on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
+    // (B) (W_hh . h_{t-1}^T) on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
     f32x4 acc[MT][4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -158,97 +192,132 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int kg = 0; kg < KG; ++kg) {
-          const f32x4 av = *reinterpret_cast<const f32x4*>(hL + ((mt * (H / 16) + kp * KG + kg) * 64 + lane) * 4);
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(hL + ((mt * (H / 16) + kp * KG + kg) * 64 + lane) * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-              acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], w[g][kg * 4 + i], acc[mt][g], 0, 0, 0);
+              acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][kg * 4 + i], hv[i], acc[mt][g], 0, 0, 0);
         }
-        if (KS > 1) {
+        if (KS > 1 && kp > 0) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * KS + kp) * 4 + g) * 64 + lane) * 4) = acc[mt][g];
+            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + kp - 1) * 4 + g) * 64 + lane) * 4) = acc[mt][g];
         }
       }
     }
     __syncthreads();   // all reads of hL done; k-split partials visible
-    // (C) gate math for this wave's rows, state update, h into LDS and y
-    float st[MT][5][RPW];
-    if (active) {
+    // (C) gate math, state update, h into LDS and y -- 4 consecutive units of one batch row per lane
+    f32x4 st[MT][4];
+    if (fin) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        f32x4 z[4];
 #pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-          float z[4];
+        for (int g = 0; g < 4; ++g) {
+          z[g] = acc[mt][g] + pre[mt][g];
+          if (KS > 1 && t > 0) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            z[g] = pick_row<KS>(acc[mt][g], kp, rr) + pre[mt][g][rr];
-            if (KS > 1 && t > 0) {
-#pragma unroll
-              for (int p2 = 0; p2 < KS; ++p2)
-                if (p2 != kp) z[g] += red[((((mt * NUG + ug) * KS + p2) * 4 + g) * 64 + lane) * 4 + kp * RPW + rr];
-            }
-          }
-          const int row = q * 4 + kp * RPW + rr;
-          const int b = b0 + mt * 16 + row;
-          const float ig = fsig(z[0]), fg = fsig(z[1]), gg = ftanh(z[2]), og = fsig(z[3]);
-          const float cn = fg * c[mt][rr] + ig * gg;
-          c[mt][rr] = cn;
-          const float hn = og * ftanh(cn);
-          st[mt][0][rr] = ig; st[mt][1][rr] = fg; st[mt][2][rr] = gg; st[mt][3][rr] = og; st[mt][4][rr] = cn;
-          hL[mt * H * 16 + hl_off(row, u)] = hn;
-          if (b < a.B) {
-            float* yp = a.y + (long)b * rowY + (long)t * H + u;
-            if (NCL > 1) tb_store_agent(yp, hn);
-            else *yp = hn;
+            for (int p2 = 0; p2 < KS - 1; ++p2)
+              z[g] += *reinterpret_cast<const f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
           }
         }
+        f32x4 hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ig = fsig(z[0][r]), fg = fsig(z[1][r]), gg = ftanh(z[2][r]), og = fsig(z[3][r]);
+          const float cn = fg * c[mt][r] + ig * gg;
+          c[mt][r] = cn;
+          hn[r] = og * ftanh(cn);
+          st[mt][0][r] = ig; st[mt][1][r] = fg; st[mt][2][r] = gg; st[mt][3][r] = og;
+        }
+        *reinterpret_cast<f32x4*>(hL + mt * H * 16 + hl_off(col, u0)) = hn;
+        stg4<(NCL > 1 ? kSC1 : 0)>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn);
       }
     }
     const bool exchange = NCL > 1 && t + 1 < T;
-    if (exchange) {
-      // Pull the other members' slices of h_t.  y was armed with the sentinel (all-ones, a NaN no
-      // finite h can equal) before the launch and every (b,t,u) is written exactly once, so the data
-      // is its own ready flag: poll with L1-bypassing 16-byte loads until no dword is the sentinel.
-      int vrows = a.B - b0;
-      if (vrows > 16 * MT) vrows = 16 * MT;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.y + (long)b0 * rowY), 0, (int)((long)vrows * rowY * 4), 0x00020000);
-      constexpr int NV = MT * 16 * (H / 4);       // float4 pieces of the whole h tile
-      constexpr int NLD = (NV + 255) / 256;
-      u32x4 buf[NLD];
-      unsigned pend = 0;
+    const bool dataflag = (a.mode & 1) != 0;
+    if (exchange && !dataflag) {
+      // publish this member's h slice: drain ONLY the y stores (the stash stores come after the flag)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
+      asm volatile("" ::: "memory");
+    }
+    if (a.train && fin) {   // BPTT stash: activated gates over P in place, cell state
 #pragma unroll
-      for (int n = 0; n < NLD; ++n) {
-        const int e = tid + 256 * n;
-        const int c4 = (e >> 4) % (H / 4);
-        if (e < NV && (c4 * 4) / US != j) pend |= 1u << n;
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[mt][g]);
+        stg4<0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, c[mt]);
       }
-      const unsigned want = pend;
-      unsigned it = 0;
-      unsigned long long t0 = 0;
-      while (pend) {
-        asm volatile("" ::: "memory");
+    }
+    if (exchange) {
+      u32x4 buf[NLD];
+      if (!dataflag) {
+        if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
+        // pull the whole tile (own slice included: one predicate-free burst) with L1-bypassing loads
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
           const int e = tid + 256 * n;
           const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-          if ((pend >> n) & 1u)
-            buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, 16);
+          buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rY, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, kSC1);
         }
+      } else {
+        // y was armed with the sentinel before the launch and every (b,t,u) is written exactly once,
+        // so the data is its own ready flag.  One idle wave polls one piece per member first (cheap
+        // on the fabric), then everyone pulls the tile and re-polls only pieces still armed.
+        if (wave == 3) {
+          if (lane < NCL && lane != j) {
+            const int voff = (int)(((long)(vrows - 1) * rowY + (long)t * H + lane * US + US - 4) * 4);
+            const unsigned long long t0 = wall_clock64();
+            unsigned it = 0;
+            while (true) {
+              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rY, voff, 0, kSC1);
+              if (v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel) break;
+              __builtin_amdgcn_s_sleep(1);
+              if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
+                atomicExch(a.err, 1);
+                *s_dead = 1;
+                break;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        if (*s_dead) break;
+        unsigned pend = 0;
 #pragma unroll
-        for (int n = 0; n < NLD; ++n)
-          if (((pend >> n) & 1u) && buf[n][0] != kSentinel && buf[n][1] != kSentinel && buf[n][2] != kSentinel &&
-              buf[n][3] != kSentinel)
-            pend &= ~(1u << n);
-        if (pend && (++it & 255u) == 0) {
-          const unsigned long long now = wall_clock64();
-          if (t0 == 0) t0 = now;
-          else if (now - t0 > a.timeout_ticks) {
-            atomicExch(a.err, 1);
-            *s_dead = 1;
-            break;
+        for (int n = 0; n < NLD; ++n) {
+          const int e = tid + 256 * n;
+          const int c4 = (e >> 4) % (H / 4);
+          if ((c4 * 4) / US != j) pend |= 1u << n;
+        }
+        bool first = true;
+        unsigned it = 0;
+        unsigned long long t0 = 0;
+        while (pend) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int n = 0; n < NLD; ++n) {
+            const int e = tid + 256 * n;
+            const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
+            if (first || ((pend >> n) & 1u))
+              buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rY, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, kSC1);
+          }
+          first = false;
+#pragma unroll
+          for (int n = 0; n < NLD; ++n)
+            if (buf[n][0] != kSentinel && buf[n][1] != kSentinel && buf[n][2] != kSentinel && buf[n][3] != kSentinel)
+              pend &= ~(1u << n);
+          if (pend && (++it & 255u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > a.timeout_ticks) {
+              atomicExch(a.err, 1);
+              *s_dead = 1;
+              break;
+            }
           }
         }
       }
@@ -256,31 +325,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       for (int n = 0; n < NLD; ++n) {
         const int e = tid + 256 * n;
         const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-        if ((want >> n) & 1u) *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
+        if ((c4 * 4) / US != j) *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
       }
     }
-    if (a.train && active) {   // BPTT stash (off the critical path): activated gates over P in place, cell state
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int rr = 0; rr < RPW; ++rr) {
-          const int b = b0 + mt * 16 + q * 4 + kp * RPW + rr;
-          if (b < a.B) {
-            float* p = a.P + (long)b * rowP + (long)t * 4 * H + u;
-            p[0] = st[mt][0][rr]; p[H] = st[mt][1][rr]; p[2 * H] = st[mt][2][rr]; p[3 * H] = st[mt][3][rr];
-            a.cst[(long)b * rowY + (long)t * H + u] = st[mt][4][rr];
-          }
-        }
-    }
     __syncthreads();   // hL complete for step t+1
-    if (NCL > 1 && *s_dead) break;   // a member timed out (uniform: read after the barrier)
+    if (NCL > 1 && *s_dead) break;
     if (t + 1 < T) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int rr = 0; rr < RPW; ++rr) pre[mt][g][rr] = nxt[mt][g][rr];
+        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[mt][g];
     }
   }
 }
@@ -291,13 +345,15 @@ struct BwdArgs {
   const float* cst;    // [B][T][H]
   const float* dy;     // [B][T][H]
   const float* Whh;    // [4H][H]
-  unsigned long long* X;   // [nclusters][2][MT*16][H][NCL] (value, tag) exchange slabs (NCL > 1)
+  float* X;            // [nclusters][3][NCL consumers][NCL producers][MT*16][US] exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
+  unsigned* flags;
   int* err;
   int B, T;
   int b_begin;
   int cl_begin;        // index of this launch's first cluster in dbpart
   int nclusters;
+  int mode;
   unsigned long long timeout_ticks;
 };
 
@@ -308,29 +364,38 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int KGD = KD / 16;
   constexpr int NTW = H >= 64 ? H / 64 : 1;        // 16-col output tiles per wave
   constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
-  constexpr int NI = MT * 16 * US / 256;           // (row,unit) items per thread
+  constexpr int QPR = US / 4;                      // unit quads per row
+  constexpr int NE = MT * 16 * QPR;                // (row, unit quad) items of the tile
+  constexpr int NQ = (NE + 255) / 256;             // items per thread
   constexpr int LDH = H + 4;                       // dhL row stride (floats)
-  static_assert(NI >= 1 && (256 % US) == 0 && (NCL == 1 || NCL % 2 == 0) && NI * (NCL > 1 ? NCL / 2 : 1) <= 32, "bad config");
+  static_assert((256 % QPR) == 0 && (NE % 256 == 0 || NE < 256), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dgL = smem;                               // [MT][KD/16][64][4]
   float* dhL = smem + MT * KD * 16;                // [MT][16][LDH] this member's partial dh_{t-1}
-  float* dbL = dhL + MT * 16 * LDH;                // [256][4] bias-grad reduction
-  int* s_dead = reinterpret_cast<int*>(dbL + 1024);
+  float* dbL = dhL + MT * 16 * LDH;                // [256][16] bias-grad reduction
+  int* s_dead = reinterpret_cast<int*>(dbL + 4096);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
   int cl, j;
-  cluster_decode(a.nclusters, NCL, cl, j);
+  cluster_decode(NCL, cl, j);
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
-  // exchange slab of this cluster: [parity][MT*16 rows][H cols][NCL members] (member fastest, so the
-  // reduce-scatter reads NCL contiguous floats per (row, unit))
-  unsigned long long* Xc = a.X + (size_t)cl * 2 * MT * 16 * H * NCL;
+  unsigned* flags = a.flags + cl * NCL;
+  constexpr int XSLAB = NCL * NCL * MT * 16 * US;  // floats per slab
+  float* Xc = a.X + (size_t)cl * 3 * XSLAB;
   if (tid == 0) *s_dead = 0;
+  int vrows = a.B - b0;
+  if (vrows > 16 * MT) vrows = 16 * MT;
+  const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + (long)b0 * rowG), 0, (int)(vrows * rowG * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cst + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)Xc, 0, NCL > 1 ? 3 * XSLAB * 4 : 0, kBufFlags);
 
-  // W_hh fragments: B[k][n] = W_hh[grow(k)][n], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
+  // W_hh fragments (A operand of the transposed product dh^T = W_hh^T . dgates^T):
+  // A[m][k] = W_hh[grow(k)][n0 + m], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
   float wb[NTW][KGD * 4];
   const bool mactive = wave < NAW;
   if (mactive) {
@@ -343,203 +408,232 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         wb[nt][s] = a.Whh[(long)grow * H + (wave * NTW + nt) * 16 + col];
       }
   }
-  // elementwise items: e = tid + 256*n -> ul = e % US (constant per thread), row, mt
-  const int ul = tid % US;
-  const int uabs = j * US + ul;
-  float dc[NI], dhrec[NI], dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+  // elementwise items: e = tid + 256*n -> unit quad qd (constant per thread), row, mt
+  const int qd = tid % QPR;
+  const int ul0 = qd * 4, uabs0 = j * US + ul0;
+  f32x4 dc[NQ], dhrec[NQ], dbacc[4];
   // stash of the current step (prefetched one step ahead): i, f, g, o, c_t, c_{t-1}, dy
-  float cur[NI][7];
+  f32x4 cur[NQ][7];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int n = 0; n < NI; ++n) {
-    dc[n] = 0.f; dhrec[n] = 0.f;
+  for (int g = 0; g < 4; ++g) dbacc[g] = zero4;
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    dc[n] = zero4; dhrec[n] = zero4;
     const int e = tid + 256 * n;
-    const int row = (e / US) & 15, mt = e / (16 * US);
-    const int b = b0 + mt * 16 + row;
-    const bool ok = b < a.B;
-    const long bb = ok ? b : 0;
-    const float* gp = a.G + bb * rowG + (long)(T - 1) * 4 * H + uabs;
-    cur[n][0] = ok ? gp[0] : 0.f; cur[n][1] = ok ? gp[H] : 0.f;
-    cur[n][2] = ok ? gp[2 * H] : 0.f; cur[n][3] = ok ? gp[3 * H] : 0.f;
-    cur[n][4] = ok ? a.cst[bb * rowY + (long)(T - 1) * H + uabs] : 0.f;
-    cur[n][5] = (ok && T > 1) ? a.cst[bb * rowY + (long)(T - 2) * H + uabs] : 0.f;
-    cur[n][6] = ok ? a.dy[bb * rowY + (long)(T - 1) * H + uabs] : 0.f;
+    const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+    const long rr = mt * 16 + row;
+    const bool ok = e < NE;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cur[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(T - 1) * 4 * H + g * H + uabs0) : zero4;
+    cur[n][4] = ok ? ldg4<0>(rC, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
+    cur[n][5] = (ok && T > 1) ? ldg4<0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
+    cur[n][6] = ok ? ldg4<0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
   }
   __syncthreads();
 
   for (int t = T - 1; t >= 0; --t) {
     // prefetch step t-1 (its c_t is this step's c_{t-1}, already held)
-    float nx[NI][6];
+    f32x4 nx[NQ][6];
     if (t > 0) {
 #pragma unroll
-      for (int n = 0; n < NI; ++n) {
+      for (int n = 0; n < NQ; ++n) {
         const int e = tid + 256 * n;
-        const int row = (e / US) & 15, mt = e / (16 * US);
-        const int b = b0 + mt * 16 + row;
-        const bool ok = b < a.B;
-        const long bb = ok ? b : 0;
-        const float* gp = a.G + bb * rowG + (long)(t - 1) * 4 * H + uabs;
-        nx[n][0] = ok ? gp[0] : 0.f; nx[n][1] = ok ? gp[H] : 0.f;
-        nx[n][2] = ok ? gp[2 * H] : 0.f; nx[n][3] = ok ? gp[3 * H] : 0.f;
-        nx[n][4] = (ok && t > 1) ? a.cst[bb * rowY + (long)(t - 2) * H + uabs] : 0.f;
-        nx[n][5] = ok ? a.dy[bb * rowY + (long)(t - 1) * H + uabs] : 0.f;
+        const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+        const long rr = mt * 16 + row;
+        const bool ok = e < NE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
+        nx[n][4] = (ok && t > 1) ? ldg4<0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
+        nx[n][5] = ok ? ldg4<0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
       }
     }
     // (A) gate gradients for this member's units
-    float dgv[NI][4];
+    f32x4 dgv[NQ][4];
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
+    for (int n = 0; n < NQ; ++n) {
       const int e = tid + 256 * n;
-      const int row = (e / US) & 15, mt = e / (16 * US);
-      const float ig = cur[n][0], fg = cur[n][1], gg = cur[n][2], og = cur[n][3];
-      const float dh = cur[n][6] + dhrec[n];
-      const float tc = ftanh(cur[n][4]);
-      const float dcn = dc[n] + dh * og * (1.f - tc * tc);
-      const float dob = dh * tc * og * (1.f - og);
-      const float di = dcn * gg * ig * (1.f - ig);
-      const float dg = dcn * ig * (1.f - gg * gg);
-      const float df = dcn * cur[n][5] * fg * (1.f - fg);
-      dc[n] = dcn * fg;
-      dgv[n][0] = di; dgv[n][1] = df; dgv[n][2] = dg; dgv[n][3] = dob;
-      dbacc[0] += di; dbacc[1] += df; dbacc[2] += dg; dbacc[3] += dob;
-      float* dl = dgL + mt * KD * 16;
-      dl[hl_off(row, ul)] = di;
-      dl[hl_off(row, US + ul)] = df;
-      dl[hl_off(row, 2 * US + ul)] = dg;
-      dl[hl_off(row, 3 * US + ul)] = dob;
+      const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ig = cur[n][0][r], fg = cur[n][1][r], gg = cur[n][2][r], og = cur[n][3][r];
+        const float dh = cur[n][6][r] + dhrec[n][r];
+        const float tc = ftanh(cur[n][4][r]);
+        const float dcn = dc[n][r] + dh * og * (1.f - tc * tc);
+        const float dob = dh * tc * og * (1.f - og);
+        const float di = dcn * gg * ig * (1.f - ig);
+        const float dg = dcn * ig * (1.f - gg * gg);
+        const float df = dcn * cur[n][5][r] * fg * (1.f - fg);
+        dc[n][r] = dcn * fg;
+        dgv[n][0][r] = di; dgv[n][1][r] = df; dgv[n][2][r] = dg; dgv[n][3][r] = dob;
+      }
+      if (e < NE) {
+        float* dl = dgL + mt * KD * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          dbacc[g] += dgv[n][g];
+          *reinterpret_cast<f32x4*>(dl + hl_off(row, g * US + ul0)) = dgv[n][g];
+        }
+      }
     }
     const bool last = t == 0;           // dh_{-1} is never used
-    const int par = t & 1;
-    const unsigned tag = (unsigned)(T - t);
+    const bool dataflag = (a.mode & 2) != 0;
+    const int par = dataflag ? t % 3 : (t & 1);   // exchange slab of this step
     if (!last) {
       __syncthreads();
-      // (B) partial dh_{t-1} = dgates_t . W_hh[rows of this member]
+      if (NCL > 1 && *s_dead) break;   // a re-poll timed out (set before the barrier: uniform)
+      // (B) partial dh_{t-1}^T = W_hh[rows of this member]^T . dgates_t^T
       if (mactive) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           f32x4 acc[NTW];
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int nt = 0; nt < NTW; ++nt) acc[nt] = zero4;
 #pragma unroll
           for (int kg = 0; kg < KGD; ++kg) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int nt = 0; nt < NTW; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], wb[nt][kg * 4 + i], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[nt][kg * 4 + i], dv[i], acc[nt], 0, 0, 0);
           }
+          // lane: batch row `col`, output units n0 .. n0+3
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
-            const int ncol = (wave * NTW + nt) * 16 + col;
-            const bool own = (ncol / US) == j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int row = q * 4 + r;
-              if (NCL == 1 || own) dhL[(mt * 16 + row) * LDH + ncol] = acc[nt][r];
-              else   // (value, step tag) in one 8-byte write-through store: the pair is its own ready flag
-                tb_store_agent_u64(Xc + (((size_t)par * MT * 16 + mt * 16 + row) * H + ncol) * NCL + j,
-                                   ((unsigned long long)tag << 32) | __float_as_uint(acc[nt][r]));
-            }
+            const int n0 = (wave * NTW + nt) * 16 + q * 4;
+            const int m = n0 / US;
+            if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
+            else stg4<kSC1>(rX, (long)par * XSLAB + ((long)(m * NCL + j) * MT * 16 + mt * 16 + col) * US + (n0 % US), acc[nt]);
           }
         }
       }
-      __syncthreads();   // own columns of dhL visible
+      if (NCL > 1 && !dataflag) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(T - t));
+        asm volatile("" ::: "memory");
+      } else {
+        __syncthreads();   // own columns of dhL visible
+      }
     }
     // dgates of this step over the gate stash, in place (after the publish: not on its critical path)
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
+    for (int n = 0; n < NQ; ++n) {
       const int e = tid + 256 * n;
-      const int row = (e / US) & 15, mt = e / (16 * US);
-      const int b = b0 + mt * 16 + row;
-      if (b < a.B) {
-        float* gp = a.G + (long)b * rowG + (long)t * 4 * H + uabs;
-        gp[0] = dgv[n][0]; gp[H] = dgv[n][1]; gp[2 * H] = dgv[n][2]; gp[3 * H] = dgv[n][3];
+      const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+      if (e < NE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) stg4<0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
       }
     }
     if (last) break;
-    // (C) reduce-scatter: dh_{t-1} for this member's units = sum over members of their partials.
-    // Every slab slot is an 8-byte (value, tag) pair written by one store, so it is its own ready
-    // flag (no store drain, no separate flag round trip): poll with L1-bypassing 16-byte loads (two
-    // pairs each) until every foreign tag equals this step's.  The slab is zeroed before the launch
-    // and tags start at 1.  Two parities: a slot is rewritten two steps later, and its writer gets
-    // there only after consuming this member's partial of the step in between, which this member
-    // produces after it has finished reading here.
-    {
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)Xc, 0, (int)((size_t)2 * MT * 16 * H * NCL * 8), 0x00020000);
-      constexpr int NQ = NCL > 1 ? NCL / 2 : 1;
-      u32x4 buf[NI][NQ];
-      unsigned pend = NCL > 1 ? (1u << (NI * NQ)) - 1u : 0u;
-      unsigned it = 0;
-      unsigned long long t0 = 0;
-      while (pend) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-          const int e = tid + 256 * n;
-          const int row = (e / US) & 15, mt = e / (16 * US);
-          const int base = (int)(((((size_t)par * MT * 16 + mt * 16 + row) * H + uabs) * NCL) * 8);
-#pragma unroll
-          for (int m2 = 0; m2 < NQ; ++m2)
-            if ((pend >> (n * NQ + m2)) & 1u) buf[n][m2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base + m2 * 16, 0, 16);
-        }
-#pragma unroll
-        for (int n = 0; n < NI; ++n)
-#pragma unroll
-          for (int m2 = 0; m2 < NQ; ++m2) {
-            const bool ready = (m2 * 2 == j || buf[n][m2][1] == tag) && (m2 * 2 + 1 == j || buf[n][m2][3] == tag);
-            if (ready) pend &= ~(1u << (n * NQ + m2));
-          }
-        if (pend && (++it & 255u) == 0) {
-          const unsigned long long now = wall_clock64();
-          if (t0 == 0) t0 = now;
-          else if (now - t0 > a.timeout_ticks) {
+    if (NCL > 1 && !dataflag && !wait_members(flags, NCL, j, (unsigned)(T - t), a.timeout_ticks, a.err, s_dead)) break;
+    if (NCL > 1 && dataflag) {
+      // Data-as-flag: the slabs are armed with the sentinel (all-ones) before the launch, a slot that
+      // holds a value is ready, and the consumer re-arms what it has consumed.  One wave polls one
+      // piece per producer (the last one it stores), then every thread pulls its pieces and re-polls
+      // only those still armed.
+      if (wave == 0 && lane < NCL && lane != j) {
+        const int voff = (int)(((long)par * XSLAB + ((long)(j * NCL + lane) * MT * 16 + MT * 16 - 1) * US + US - 4) * 4);
+        const unsigned long long t0 = wall_clock64();
+        unsigned it = 0;
+        while (true) {
+          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rX, voff, 0, kSC1);
+          if (v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
             atomicExch(a.err, 1);
             *s_dead = 1;
             break;
           }
         }
       }
+      __syncthreads();
+      if (*s_dead) break;
+    }
+    // (C) reduce-scatter: dh_{t-1} for this member's units = own partial + the other members' partials
+    // (every slot is loaded, the never-written own one included: one predicate-free burst)
 #pragma unroll
-      for (int n = 0; n < NI; ++n) {
-        const int e = tid + 256 * n;
-        const int row = (e / US) & 15, mt = e / (16 * US);
-        float s = dhL[(mt * 16 + row) * LDH + uabs];
+    for (int n = 0; n < NQ; ++n) {
+      const int e = tid + 256 * n;
+      const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+      if (e < NE) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(dhL + (mt * 16 + row) * LDH + uabs0);
         if (NCL > 1) {
+          const long base = (long)par * XSLAB + ((long)(j * NCL) * MT * 16 + mt * 16 + row) * US + ul0;
+          f32x4 v[NCL];
 #pragma unroll
-          for (int m2 = 0; m2 < NQ; ++m2) {
-            if (m2 * 2 != j) s += __uint_as_float(buf[n][m2][0]);
-            if (m2 * 2 + 1 != j) s += __uint_as_float(buf[n][m2][2]);
+          for (int m = 0; m < NCL; ++m) v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
+          if (dataflag) {
+            unsigned pend = 0;
+#pragma unroll
+            for (int m = 0; m < NCL; ++m) {
+              const u32x4 b = __builtin_bit_cast(u32x4, v[m]);
+              if (m != j && (b[0] == kSentinel || b[1] == kSentinel || b[2] == kSentinel || b[3] == kSentinel)) pend |= 1u << m;
+            }
+            unsigned it = 0;
+            unsigned long long t0 = 0;
+            while (pend) {   // rare: a piece behind the polled one
+              asm volatile("" ::: "memory");
+#pragma unroll
+              for (int m = 0; m < NCL; ++m)
+                if ((pend >> m) & 1u) {
+                  v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
+                  const u32x4 b = __builtin_bit_cast(u32x4, v[m]);
+                  if (b[0] != kSentinel && b[1] != kSentinel && b[2] != kSentinel && b[3] != kSentinel) pend &= ~(1u << m);
+                }
+              if (pend && (++it & 255u) == 0) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > a.timeout_ticks) {
+                  atomicExch(a.err, 1);
+                  *s_dead = 1;
+                  break;
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < NCL; ++m) {
+            const bool other = m != j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] += other ? v[m][r] : 0.f;
+          }
+          if (dataflag) {
+            // Re-arm what was consumed.  The slab of step t is written again at step t-3; its writer
+            // gets there only after consuming this member's partial of step t-2, which is stored
+            // after the barrier that follows the NEXT step's copy of this wait -- and that wait
+            // covers these stores.  So the re-arm always lands before the next write.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4 armed = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+#pragma unroll
+            for (int m = 0; m < NCL; ++m)
+              if (m != j) stg4<kSC1>(rX, base + (long)m * MT * 16 * US, armed);
           }
         }
         dhrec[n] = s;
       }
     }
-    if (NCL > 1) {
-      // a timed-out member must stop the whole workgroup: make the verdict uniform
-      __syncthreads();
-      if (*s_dead) break;
-    }
+    if (NCL == 1) __syncthreads();   // dhL free for the next step (NCL > 1: the waits' barriers order it)
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
+    for (int n = 0; n < NQ; ++n) {
       cur[n][4] = cur[n][5];
       cur[n][0] = nx[n][0]; cur[n][1] = nx[n][1]; cur[n][2] = nx[n][2]; cur[n][3] = nx[n][3];
       cur[n][5] = nx[n][4]; cur[n][6] = nx[n][5];
     }
   }
-  // bias grads of this cluster: reduce the threads that share a unit, one partial row per cluster
+  // bias grads of this cluster: reduce the threads that share a unit quad, one partial row per cluster
   __syncthreads();
 #pragma unroll
-  for (int g = 0; g < 4; ++g) dbL[tid * 4 + g] = dbacc[g];
+  for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dbL + tid * 16 + g * 4) = dbacc[g];
   __syncthreads();
-  if (tid < US) {
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = tid; k < 256; k += US)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) s[g] += dbL[k * 4 + g];
-    float* out = a.dbpart + (size_t)(a.cl_begin + cl) * 4 * H;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) out[g * H + j * US + tid] = s[g];
+  if (tid < 4 * US) {
+    const int g = tid / US, ul = tid % US;
+    constexpr int NTH = NE < 256 ? NE : 256;
+    float s = 0.f;
+    for (int th = ul / 4; th < NTH; th += QPR) s += dbL[th * 16 + g * 4 + (ul & 3)];
+    a.dbpart[(size_t)(a.cl_begin + cl) * 4 * H + g * H + j * US + ul] = s;
   }
 }
 
@@ -587,8 +681,8 @@ bool make_plan(int H, int B, Plan& p) {
   p.rows_per_cluster = 16 * MT;
   p.clusters_per_launch = max_clusters;
   const int NUG = US / 16;
-  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS > 1 ? KS : 0) * NUG * MT * 4 * 256) * 4 + 16;
-  p.lds_bwd = ((size_t)MT * 4 * US * 16 + (size_t)MT * 16 * (H + 4) + 1024) * 4 + 16;
+  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
+  p.lds_bwd = ((size_t)MT * 4 * US * 16 + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
   return true;
 }
 
@@ -645,30 +739,53 @@ int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
 
 constexpr unsigned long long kTimeoutTicks = 200000000ull;   // 2 s of the 100 MHz realtime counter
 
-// workspace carve: [bias sum | dbpart | X | gemm split-k slabs]
+// Exchange protocol, bit 0 forward / bit 1 backward: 1 = data-as-flag (sentinel-armed buffers, no
+// store drain and no counter round trip; the default), 0 = drained write-through stores + per-member
+// step counters (Guideline 16 R1).  TB_LSTM_MODE overrides it (A/B measurements).
+int exchange_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("TB_LSTM_MODE");
+    mode = e ? atoi(e) : 3;
+  }
+  return mode;
+}
+
+// the kernels address one cluster's rows through 32-bit buffer descriptors
+bool tile_fits_descriptor(const Plan& p, int T, int H) {
+  return (long long)p.rows_per_cluster * T * 4 * H * 4 < 0x7FFFFFFFll;
+}
+
+// workspace carve: [flags | bias sum | dbpart | X | gemm split-k slabs]
 struct Carve {
+  unsigned* flags; size_t flags_bytes;
   float* bsum;
   float* dbpart;
-  unsigned long long* X; size_t x_bytes;
+  float* X; size_t x_bytes;
   float* gemm_ws; size_t gemm_ws_bytes;
 };
 
 size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   size_t off = 0;
+  const size_t flags_bytes = tb_align_up((size_t)ncl_total * p.NCL * sizeof(unsigned), 256);
   const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
   const size_t x_bytes = (bwd && p.NCL > 1)
-                             ? tb_align_up((size_t)ncl_launch * 2 * p.NCL * p.rows_per_cluster * H * sizeof(unsigned long long), 256)
+                             ? tb_align_up((size_t)ncl_launch * 3 * p.NCL * p.rows_per_cluster * H * sizeof(float), 256)
                              : 0;
   const int widest = in_dim > H ? in_dim : H;
   const size_t gemm_bytes = bwd ? tb_align_up((size_t)64 * 4 * H * widest * sizeof(float), 256) : 0;
+  if (c) {
+    c->flags = reinterpret_cast<unsigned*>(base + off); c->flags_bytes = flags_bytes;
+  }
+  off += flags_bytes;
   if (c) c->bsum = reinterpret_cast<float*>(base + off);
   off += bsum_bytes;
   if (c) c->dbpart = reinterpret_cast<float*>(base + off);
   off += dbpart_bytes;
-  if (c) { c->X = reinterpret_cast<unsigned long long*>(base + off); c->x_bytes = x_bytes; }
+  if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
   off += x_bytes;
   if (c) {
     c->gemm_ws = reinterpret_cast<float*>(base + off);
@@ -707,8 +824,10 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   Carve c;
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
-  // arm y with the sentinel the cluster members poll on (see lstm_fwd_kernel)
-  if (p.NCL > 1) TB_HIP(hipMemsetAsync(y, 0xFF, (size_t)B * T * H * sizeof(float), s));
+  if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: T*H too large (%d x %d)", T, H);
+  const int mode = exchange_mode();
+  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
+  if (p.NCL > 1 && (mode & 1)) TB_HIP(hipMemsetAsync(y, 0xFF, (size_t)B * T * H * sizeof(float), s));
   // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash
   const float* bias = nullptr;
   if (b_ih && b_hh) {
@@ -726,11 +845,13 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     FwdArgs a;
     a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
+    a.flags = c.flags + (size_t)c0 * p.NCL;
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.nclusters = ncl;
     a.train = train;
+    a.mode = mode;
     a.timeout_ticks = kTimeoutTicks;
     rc = launch_fwd(p, a, ncl * p.NCL, s);
     if (rc) return rc;
@@ -753,6 +874,8 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   Carve c;
   const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
+  if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: T*H too large (%d x %d)", T, H);
+  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   int rc;
   // algorithmic bytes of one layer backward: read 5h stash + dy, read x, write dx
@@ -763,11 +886,13 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     a.G = gates; a.cst = cstash; a.dy = dy; a.Whh = w_hh;
     a.X = c.X;
     a.dbpart = c.dbpart;
+    a.flags = c.flags + (size_t)c0 * p.NCL;
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.cl_begin = c0;
-    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.X, 0, c.x_bytes, s));   // tags start below 1
+    a.mode = exchange_mode();
+    if (p.NCL > 1 && (a.mode & 2)) TB_HIP(hipMemsetAsync(c.X, 0xFF, c.x_bytes, s));   // arm the slabs
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
     rc = launch_bwd(p, a, ncl * p.NCL, s);
