@@ -9,16 +9,21 @@
 //
 // LAY_A = 0: A stored [M][K] (k contiguous).   LAY_A = 1: A stored [K][M] (m contiguous).
 // LAY_B = 0: B stored [N][K] (k contiguous).   LAY_B = 1: B stored [K][N] (n contiguous).
-// Block tile 64x64x16, 4 waves as 2x2, each wave 2x2 MFMA tiles of 16x16.  Operand tiles are
-// staged k-major in LDS with an 80-float row stride so the per-lane MFMA operand reads
-// (lane -> [k = lane>>4][row = lane&15]) hit 32 distinct banks per half-wave.
-// Split-K (gridDim.z) writes partial slabs that splitk_reduce sums in a fixed order
-// (bitwise reproducible; no float atomics).
+//
+// Block tile BM x BN x 16 with 4 waves laid out WGM x WGN, each wave a (BM/WGM) x (BN/WGN) patch of
+// 16x16 MFMA tiles (128x128 as 2x2 waves of 4x4 tiles for wide outputs; 256x64 / 256x32 as 4x1 for
+// the narrow ones), 32 flop per staged byte.  Operand tiles keep their global orientation in LDS
+// (no transposing stores): a k-contiguous tile is [rows][16+4] and one ds_read_b128 per lane yields
+// the operand of 4 k-steps, an m-contiguous tile is [16][rows+4] read with 4 ds_read_b32; both use
+// the k order k = (lane>>4)*4 + step, so any layout pair multiplies correctly.  Two LDS stages, one
+// barrier per k-tile, next tile's global loads in flight under the MFMAs.
+// Split-K (gridDim.z) writes partial slabs that splitk_reduce sums in a fixed order (bitwise
+// reproducible; no float atomics).
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 80;
+constexpr int BK = 16;
 
 struct GemmArgs {
   const float* A;
@@ -35,122 +40,150 @@ struct GemmArgs {
   int vecA, vecB;
 };
 
-// One operand tile (64 rows x 16 k) global -> registers.
-template <int LAY>
-__device__ __forceinline__ void tile_load(const float* __restrict__ src, long ld, int r0, int rlim, int k0,
-                                          int klim, int vec, int shift, int period, float (&v)[4]) {
-  const int t = threadIdx.x;
-  if (LAY == 0) {
-    const int r = r0 + (t >> 2);
-    const int k = k0 + (t & 3) * 4;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (r < rlim) {
-      const float* p = src + (long)r * ld + k;
-      if (vec && k + 3 < klim) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
-        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-      } else {
+template <int LAY, int ROWS>
+struct Tile {
+  static constexpr int LD = LAY == 0 ? BK + 4 : ROWS + 4;            // LDS row stride (floats)
+  static constexpr int FLOATS = LAY == 0 ? ROWS * LD : BK * LD;      // one stage
+  static constexpr int NCHUNK = ROWS * BK / 4;                       // 16-byte chunks of one stage
+  static constexpr int NCH = (NCHUNK + 255) / 256;                   // chunks per thread
+  static_assert(NCHUNK % 256 == 0 || NCHUNK < 256, "chunk count must tile the block");
+
+  // chunk c of this thread -> (row, k) of its first element
+  static __device__ __forceinline__ void where(int c, int& r, int& k) {
+    const int e = threadIdx.x + 256 * c;
+    if (LAY == 0) { r = e >> 2; k = (e & 3) * 4; }
+    else { k = e / (ROWS / 4); r = (e % (ROWS / 4)) * 4; }
+  }
+
+  static __device__ __forceinline__ void load(const float* __restrict__ src, long ld, int r0, int rlim, int k0,
+                                              int klim, int vec, int shift, int period, f32x4 (&v)[NCH]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (k + i < klim) v[i] = p[i];
-      }
-    }
-  } else {
-    int k = k0 + (t >> 4);
-    const int r = r0 + (t & 15) * 4;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    bool ok = k < klim;
-    if (shift) {
-      ok = ok && (k % period) >= shift;
-      k -= shift;
-    }
-    if (ok) {
-      const float* p = src + (long)k * ld + r;
-      if (vec && r + 3 < rlim) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(p);
-        v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
-      } else {
+    for (int c = 0; c < NCH; ++c) {
+      int r, k;
+      where(c, r, k);
+      r += r0; k += k0;
+      v[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (NCHUNK < 256 && threadIdx.x >= NCHUNK) continue;
+      if (LAY == 0) {
+        if (r < rlim && k < klim) {
+          const float* p = src + (long)r * ld + k;
+          if (vec && k + 3 < klim) v[c] = *reinterpret_cast<const f32x4*>(p);
+          else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (r + i < rlim) v[i] = p[i];
+            for (int i = 0; i < 4; ++i)
+              if (k + i < klim) v[c][i] = p[i];
+          }
+        }
+      } else {
+        bool ok = k < klim && r < rlim;
+        if (shift) {   // B row k is source row k - shift, zero for the first `shift` rows of each period
+          ok = ok && (k % period) >= shift;
+          k -= shift;
+        }
+        if (ok) {
+          const float* p = src + (long)k * ld + r;
+          if (vec && r + 3 < rlim) v[c] = *reinterpret_cast<const f32x4*>(p);
+          else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (r + i < rlim) v[c][i] = p[i];
+          }
+        }
       }
     }
   }
-}
 
-template <int LAY>
-__device__ __forceinline__ void tile_store(float* sm, const float (&v)[4]) {
-  const int t = threadIdx.x;
-  if (LAY == 0) {
-    const int r = t >> 2, k = (t & 3) * 4;
+  static __device__ __forceinline__ void store(float* sm, const f32x4 (&v)[NCH]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sm[(k + i) * LDT + r] = v[i];
-  } else {
-    const int k = t >> 4, r = (t & 15) * 4;
-    f32x4 x = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(&sm[k * LDT + r]) = x;
+    for (int c = 0; c < NCH; ++c) {
+      int r, k;
+      where(c, r, k);
+      if (NCHUNK < 256 && threadIdx.x >= NCHUNK) continue;
+      if (LAY == 0) *reinterpret_cast<f32x4*>(sm + r * LD + k) = v[c];
+      else *reinterpret_cast<f32x4*>(sm + k * LD + r) = v[c];
+    }
   }
-}
 
-template <int LAY_A, int LAY_B>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[BK * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+  // MFMA operand of the 16 rows starting at `row`, for the 4 k-steps of one k-tile
+  static __device__ __forceinline__ f32x4 frag(const float* sm, int row, int col, int q) {
+    if (LAY == 0) return *reinterpret_cast<const f32x4*>(sm + (row + col) * LD + q * 4);
+    f32x4 f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = sm[(q * 4 + i) * LD + row + col];
+    return f;
+  }
+};
+
+template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
+  using TA = Tile<LAY_A, BM>;
+  using TB = Tile<LAY_B, BN>;
+  constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;
+  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad wave layout");
+  __shared__ __attribute__((aligned(16))) float As[2][TA::FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][TB::FLOATS];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
   const int kbeg = z * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, q = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float ra[4], rb[4];
+  f32x4 ra[TA::NCH], rb[TB::NCH];
   if (kbeg < kend) {
-    tile_load<LAY_A>(a.A, a.lda, m0, a.M, kbeg, kend, a.vecA, 0, 1, ra);
-    tile_load<LAY_B>(a.B, a.ldb, n0, a.N, kbeg, kend, a.vecB, a.b_shift, a.b_period, rb);
+    TA::load(a.A, a.lda, m0, a.M, kbeg, kend, a.vecA, 0, 1, ra);
+    TB::load(a.B, a.ldb, n0, a.N, kbeg, kend, a.vecB, a.b_shift, a.b_period, rb);
+    TA::store(As[0], ra);
+    TB::store(Bs[0], rb);
   }
+  __syncthreads();
+  int st = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();  // previous tile fully consumed
-    tile_store<LAY_A>(As, ra);
-    tile_store<LAY_B>(Bs, rb);
-    __syncthreads();
-    if (k0 + BK < kend) {  // next tile's global loads fly under this tile's MFMAs
-      tile_load<LAY_A>(a.A, a.lda, m0, a.M, k0 + BK, kend, a.vecA, 0, 1, ra);
-      tile_load<LAY_B>(a.B, a.ldb, n0, a.N, k0 + BK, kend, a.vecB, a.b_shift, a.b_period, rb);
+    const bool more = k0 + BK < kend;
+    if (more) {   // next tile's global loads fly under this tile's MFMAs
+      TA::load(a.A, a.lda, m0, a.M, k0 + BK, kend, a.vecA, 0, 1, ra);
+      TB::load(a.B, a.ldb, n0, a.N, k0 + BK, kend, a.vecB, a.b_shift, a.b_period, rb);
     }
+    f32x4 af[TM], bf[TN];
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      const int kr = (ks * 4 + q) * LDT;
-      const float a0 = As[kr + wm * 32 + col];
-      const float a1 = As[kr + wm * 32 + 16 + col];
-      const float b0 = Bs[kr + wn * 32 + col];
-      const float b1 = Bs[kr + wn * 32 + 16 + col];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int i = 0; i < TM; ++i) af[i] = TA::frag(As[st], (wm * TM + i) * 16, col, q);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = TB::frag(Bs[st], (wn * TN + j) * 16, col, q);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    if (more) {
+      TA::store(As[st ^ 1], ra);
+      TB::store(Bs[st ^ 1], rb);
     }
+    __syncthreads();
+    st ^= 1;
   }
 
   float* out = a.splits > 1 ? a.slab + (size_t)z * a.M * a.N : a.C;
   const long ldo = a.splits > 1 ? a.N : a.ldc;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int n = n0 + wn * 32 + ni * 16 + col;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 16 + col;
       if (n >= a.N) continue;
       const float bv = (a.splits == 1 && a.bias) ? a.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + mi * 16 + q * 4 + r;
+        const int m = m0 + (wm * TM + i) * 16 + q * 4 + r;
         if (m >= a.M) continue;
-        float v = acc[mi][ni][r] + bv;
+        float v = acc[i][j][r] + bv;
         if (a.splits == 1) {
           if (a.act == 1) v = tanhf(v);
           else if (a.act == 2) v = tb_sigmoid(v);
@@ -175,6 +208,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
   }
 }
 
+template <int BM, int BN, int WGM, int WGN>
+void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
+  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+}
+
 }  // namespace
 
 // Host-side launcher shared by the C-ABI entry points (capi.hip, lstm.hip).
@@ -193,11 +234,14 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   a.b_period = b_period > 0 ? b_period : 1;
   a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  // tile shape by output width
+  const int cfg = N <= 32 ? 0 : (N <= 64 ? 1 : 2);
+  const int BM = cfg == 2 ? 128 : 256, BN = cfg == 0 ? 32 : (cfg == 1 ? 64 : 128);
   const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
   const long tiles = (long)mt * nt;
   int splits = 1;
   const int cus = tb_num_cus();
-  if (tiles < cus && K >= 64 * BK) {
+  if (tiles < cus && K >= 64 * BK && ws) {
     splits = (int)((2L * cus + tiles - 1) / tiles);
     const int maxs = K / (16 * BK);
     if (splits > maxs) splits = maxs;
@@ -213,10 +257,9 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   a.slab = ws;
   dim3 grid(mt, nt, splits);
   tb_prof_begin(TB_K_GEMM, stream);
-  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, dim3(256), 0, stream, a);
-  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, dim3(256), 0, stream, a);
-  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0>), grid, dim3(256), 0, stream, a);
+  if (cfg == 0) launch_cfg<256, 32, 4, 1>(a, transA, transB, grid, stream);
+  else if (cfg == 1) launch_cfg<256, 64, 4, 1>(a, transA, transB, grid, stream);
+  else launch_cfg<128, 128, 2, 2>(a, transA, transB, grid, stream);
   TB_LAUNCH_CHECK("gemm_f32_kernel");
   if (splits > 1) {
     const long total = (long)M * N;
