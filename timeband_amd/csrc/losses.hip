@@ -134,26 +134,49 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ a, long rows, int cols, float* __restrict__ out,
-                              double* part) {
-  // out[c] = sum_r a[r][c]; block b handles a slice of rows for all columns, then block 0.. reduce
-  // via `part` [gridDim.x][cols] (two launches: this kernel with out == nullptr, then final).
-  const int c = blockIdx.y * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// out[c] = sum_r a[r][c] in two launches.  Block (x, y): rows slice x, columns [y*cw, (y+1)*cw); the 256
+// threads are 256/cw row lanes x cw columns (cw a power of two <= 64, so narrow matrices still use
+// every lane and each block-iteration reads 256 consecutive floats); double accumulation, fixed order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, long rows, int cols, int cw,
+                                                     double* __restrict__ part) {
+  __shared__ double sh[256];
+  const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, rpb = 256 / cw;
+  const int c = blockIdx.y * cw + tx;
   const long per = (rows + gridDim.x - 1) / gridDim.x;
   const long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   double s = 0.0;
-  for (long r = r0; r < r1; ++r) s += (double)a[r * cols + c];
-  part[(size_t)blockIdx.x * cols + c] = s;
-  (void)out;
+  if (c < cols) {
+    long r = r0 + ty;
+    for (; r + 3L * rpb < r1; r += 4L * rpb) {   // 4 independent loads in flight
+      const float v0 = a[r * cols + c], v1 = a[(r + rpb) * cols + c], v2 = a[(r + 2L * rpb) * cols + c],
+                  v3 = a[(r + 3L * rpb) * cols + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; r < r1; r += rpb) s += (double)a[r * cols + c];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    double t = 0.0;
+    for (int k = 0; k < rpb; ++k) t += sh[k * cw + tx];
+    part[(size_t)blockIdx.x * cols + c] = t;
+  }
 }
 
-__global__ void colsum_final_kernel(const double* __restrict__ part, int nparts, int cols, float* out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(64) void colsum_final_kernel(const double* __restrict__ part, int nparts, int cols,
+                                                          float* out) {
+  // one wave per column: lanes stride the partials, then a fixed-order tree over the lanes
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
-  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * cols + c];
-  out[c] = (float)s;
+  for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * cols + c];
+  __shared__ double sh[64];
+  sh[lane] = s;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (lane < w) sh[lane] += sh[lane + w];
+    __syncthreads();
+  }
+  if (lane == 0) out[c] = (float)sh[0];
 }
 
 // torch.optim.Adam (no weight decay / amsgrad); operation order follows torch's single-tensor path
@@ -261,19 +284,28 @@ int tb_act_bwd(const float* dy, const float* y, float* dz, long n, int act, void
   return TB_OK;
 }
 
-size_t tb_colsum_workspace_bytes(int cols) { return (size_t)64 * cols * sizeof(double) + 256; }
+constexpr int kColsumMaxParts = 1024;
+
+size_t tb_colsum_workspace_bytes(int cols) { return (size_t)kColsumMaxParts * cols * sizeof(double) + 256; }
 
 int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (cols <= 0) return TB_OK;
+  if (!a || !out || !ws) return tb_set_error(TB_ERR_ARG, "colsum: null pointer");
   if (ws_bytes < tb_colsum_workspace_bytes(cols)) return tb_set_error(TB_ERR_WORKSPACE, "colsum: workspace too small");
-  int parts = (int)(rows / 64);
+  int cw = 1;
+  while (cw < cols && cw < 64) cw *= 2;
+  const int ycount = (cols + cw - 1) / cw;
+  // enough blocks to fill the chip, each with at least ~64 block-iterations of rows
+  long parts = rows / (64L * (256 / cw));
+  const long want = (4L * tb_num_cus() + ycount - 1) / ycount;
+  if (parts > want) parts = want;
+  if (parts > kColsumMaxParts) parts = kColsumMaxParts;
   if (parts < 1) parts = 1;
-  if (parts > 64) parts = 64;
   double* part = static_cast<double*>(ws);
-  hipLaunchKernelGGL(colsum_kernel, dim3(parts, (cols + 63) / 64), dim3(64), 0, s, a, rows, cols, out, part);
+  hipLaunchKernelGGL(colsum_kernel, dim3((int)parts, ycount), dim3(256), 0, s, a, rows, cols, cw, part);
   TB_LAUNCH_CHECK("colsum_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 63) / 64), dim3(64), 0, s, part, parts, cols, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(64), 0, s, part, (int)parts, cols, out);
   TB_LAUNCH_CHECK("colsum_final_kernel");
   return TB_OK;
 }

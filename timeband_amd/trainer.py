@@ -2,7 +2,8 @@
 
 Same constructor, config keys, `train` / `train_step` / `model_update` behaviour and step
 semantics as the reference's Gen-A trainer, including its quirks:
-  * critic loop with a FRESH RMSprop per batch and a non-detached fake_y (trainer.py:142-158);
+  * critic loop with a FRESH RMSprop per batch (trainer.py:142-158); the reference's non-detached
+    fake_y there only produces G gradients that are zeroed unread, so they are not computed;
   * `zero_grad` of D and G once per iteration, before the D phase (:160-161), so the generator
     step uses D-phase + G-phase gradients;
   * Adam re-created every epoch (:95-98);
@@ -87,7 +88,11 @@ class TIMEBANDTrainer:
     def critic_step(self, true_x, true_y):
         """trainer.py:143-158 for one draw."""
         netD, netG = self.models.netD, self.models.netG
-        fake_y = netG(true_x)
+        # The reference keeps fake_y's graph here (trainer.py:147-152), so errD.backward() also fills
+        # G's gradients -- which optimG.zero_grad() (:161) discards before anything reads them.  Dead
+        # work with no effect on any result: G runs without a graph (and without the BPTT stash).
+        with torch.no_grad():
+            fake_y = netG(true_x)
         self._critic_opt.zero_grad()
         Dy, DGx = netD(true_y), netD(fake_y)
         errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx, critic=True)
@@ -136,13 +141,23 @@ class TIMEBANDTrainer:
             errD.backward()
             self.optimD.all_reduce_grads()
             self.optimD.step()
-        # generator phase
-        with torch.set_grad_enabled(training):
-            fake_y = netG(true_x)
-            DGx = netD(fake_y)
-            errG = self.losses.gen_loss(true_y, fake_y, DGx)
+        # generator phase.  errG.backward() of the reference also accumulates into D's parameter
+        # gradients (trainer.py:183-186); the next zero_grad (:146 / :160) clears them unread, so D's
+        # weight gradients are not computed here -- only the path through D back to fake_y.
+        dparams = [p for p in netD.parameters() if p.requires_grad] if training else []
+        for p in dparams:
+            p.requires_grad_(False)
+        try:
+            with torch.set_grad_enabled(training):
+                fake_y = netG(true_x)
+                DGx = netD(fake_y)
+                errG = self.losses.gen_loss(true_y, fake_y, DGx)
+            if training:
+                errG.backward()
+        finally:
+            for p in dparams:
+                p.requires_grad_(True)
         if training:
-            errG.backward()
             self.optimG.all_reduce_grads()
             self.optimG.step()
         return fake_y.detach()
