@@ -54,6 +54,22 @@ class _Log:
     warn = debug = info
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the latest committed rocprofv3 PMC summary
+    (profiles/r*_traffic.json, made by tools/gpu_profile.sh + tools/pmc_summary.py from separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command; counters cannot be read inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            fam = json.load(f)["families"].get(family)
+        return (round(fam["hbm_bytes_per_launch"], 1), os.path.basename(files[-1])) if fam else (None, None)
+    except Exception:
+        return None, None
+
+
 def build(cfg, device, seed=31):
     from timeband_amd import synthetic
     from timeband_amd.dataset import TIMEBANDDataset
@@ -161,6 +177,7 @@ def main():
         p = prof[dom]
         achieved = p["algo_bytes"] / (p["total_ms"] * 1e-3) / 1e9 if p["total_ms"] > 0 else 0.0
         abw = algo_bytes_per_window(**cfg)
+        traffic, traffic_src = pmc_traffic(f"{dom}_kernel") if args.config == "cfg2" else (None, None)
         out = {
             "metric": "G+D training windows/sec", "value": round(value, 2), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,7 +189,8 @@ def main():
                        "parallelism": f"dp{world}", "full_iteration": bool(args.full)},
             "roofline": {"bound": "hbm", "kernel": f"{dom}_kernel (persistent recurrent, all LSTM layers)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "launches": p["launches"],
                          "avg_launch_ms": round(p["total_ms"] / max(1, p["launches"]), 4),
                          "algo_bytes_per_launch": round(p["algo_bytes"] / max(1, p["launches"]), 1)},

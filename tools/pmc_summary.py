@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""HBM traffic per kernel from the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: they cannot share a
+pass on gfx950).  Units and corrections follow MI355X_MICROARCH.md (HBM section): the counters are in KiB;
+on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B per lane) coalesced reads at 64 bytes, so
+the read side is doubled for kernels whose loads are 16-byte wide (all of ours); WRITE_SIZE is exact for
+16-byte stores.
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    per = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == counter:
+                per[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
+    return per
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)
+
+
+def family(n):
+    for f in ("lstm_fwd_kernel", "lstm_bwd_kernel", "gemm"):
+        if f in n:
+            return f
+    return None
+
+
+fetch = load(sys.argv[1], "FETCH_SIZE")
+write = load(sys.argv[2], "WRITE_SIZE")
+rows, fam = [], defaultdict(lambda: [0, 0.0, 0.0])
+for k in sorted(set(fetch) | set(write), key=lambda k: -(sum(fetch.get(k, [])) * 2 + sum(write.get(k, [])))):
+    n = max(len(fetch.get(k, [])), len(write.get(k, [])))
+    fr, wr = sum(fetch.get(k, [])), sum(write.get(k, []))
+    rows.append(dict(kernel=short(k), launches=n, fetch_raw_bytes_per_launch=fr / n, fetch_corrected_bytes_per_launch=2 * fr / n,
+                     write_bytes_per_launch=wr / n, hbm_bytes_per_launch=(2 * fr + wr) / n))
+    f = family(k)
+    if f:
+        fam[f][0] += n
+        fam[f][1] += 2 * fr
+        fam[f][2] += wr
+out = dict(note="FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes; separate PMC passes of bench.py --steps 2 --warmup 1",
+           families={f: dict(launches=v[0], hbm_bytes_per_launch=(v[1] + v[2]) / max(1, v[0]),
+                             read_bytes_per_launch=v[1] / max(1, v[0]), write_bytes_per_launch=v[2] / max(1, v[0]))
+                     for f, v in fam.items()},
+           kernels=rows)
+for r in rows[:25]:
+    print(f"{r['kernel'][:60]:60s} n={r['launches']:4d} read={r['fetch_corrected_bytes_per_launch'] / 1e6:9.2f} MB write={r['write_bytes_per_launch'] / 1e6:9.2f} MB")
+for f, v in out["families"].items():
+    print(f"family {f}: {v['launches']} launches, {v['hbm_bytes_per_launch'] / 1e6:.2f} MB/launch")
+if len(sys.argv) > 3:
+    with open(sys.argv[3], "w") as fo:
+        json.dump(out, fo, indent=1)
