@@ -7,6 +7,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 #define TB_OK 0
 #define TB_ERR_ARG 1
 #define TB_ERR_HIP 2
@@ -51,6 +54,42 @@ __device__ __forceinline__ void tb_store_agent_u64(unsigned long long* p, unsign
 }
 __device__ __forceinline__ unsigned tb_load_agent_u32(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- split-precision bf16 operands ("bf16x3") ------------------------------------------------
+// An fp32 value x is carried as two bf16 values hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to
+// ~2^-17 relative).  A product a.b is then three bf16 MFMAs with fp32 accumulation,
+// a_hi.b_hi + a_hi.b_lo + a_lo.b_hi (the dropped lo.lo term is ~2^-18 relative): fp32-grade results
+// at 16/3 of the fp32 MFMA rate (v_mfma_f32_16x16x32_bf16 is 16x the rate of v_mfma_f32_16x16x4_f32).
+__device__ __forceinline__ unsigned tb_cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0,%1,%2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// two fp32 values -> packed bf16 pair of the high parts and packed pair of the residuals
+__device__ __forceinline__ void tb_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = tb_cvt_pk_bf16(a, b);
+  lo = tb_cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
+__device__ __forceinline__ void tb_split4(f32x4 v, u32x2& hi, u32x2& lo) {
+  unsigned h0, l0, h1, l1;
+  tb_split2(v[0], v[1], h0, l0);
+  tb_split2(v[2], v[3], h1, l1);
+  hi = (u32x2){h0, h1};
+  lo = (u32x2){l0, l1};
+}
+__device__ __forceinline__ void tb_split8(f32x4 a, f32x4 b, bf16x8& hi, bf16x8& lo) {
+  u32x2 h0, l0, h1, l1;
+  tb_split4(a, h0, l0);
+  tb_split4(b, h1, l1);
+  hi = __builtin_bit_cast(bf16x8, (u32x4){h0[0], h0[1], h1[0], h1[1]});
+  lo = __builtin_bit_cast(bf16x8, (u32x4){l0[0], l0[1], l1[0], l1[1]});
+}
+// acc += a.b with both operands split (small terms first)
+__device__ __forceinline__ f32x4 tb_mfma_bf16x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
 }
 
 // profiling hooks (capi.hip): HIP-event timing of one kernel family on its own stream

@@ -55,12 +55,6 @@ struct FwdArgs {
   unsigned long long timeout_ticks;
 };
 
-__device__ __forceinline__ int hl_off(int row, int k) {
-  // LDS image of a [16][K] tile laid out so that one ds_read_b128 per lane yields the MFMA
-  // operand of 4 consecutive k-steps: float offset of element (row, k).
-  return (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + row) << 2) + (k & 3);
-}
-
 // cluster/member decode: keep the members of a cluster on blocks with equal (blockIdx % 8), i.e.
 // on one XCD under the observed round-robin placement (speed only; correctness never depends on it)
 __device__ __forceinline__ void cluster_decode(int NCL, int& cl, int& j) {
@@ -117,18 +111,22 @@ template <int H, int US, int KS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NUG = US / 16;          // 16-unit groups per member
   constexpr int NCL = H / US;           // members per cluster
-  constexpr int KPER = H / KS;          // k range per wave
-  constexpr int KG = KPER / 16;         // 16-wide k groups per wave
+  constexpr int HK = H < 32 ? 32 : H;   // k extent, padded to one MFMA k-step
+  constexpr int KPER = HK / KS;         // k range per wave
+  constexpr int NKS = KPER / 32;        // 32-deep MFMA k-steps per wave
+  constexpr int LDH = HK + 8;           // LDS row stride of the h tile (bf16 elements; 16-byte pad)
   constexpr int NACT = NUG * KS;        // waves doing MFMA work
   constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
   constexpr int NV = MT * 16 * (H / 4); // 16-byte pieces of the whole h tile
   constexpr int NLD = (NV + 255) / 256;
-  static_assert(NACT <= 4 && KPER % 16 == 0 && H % US == 0 && (NCL == 1 || NV % 256 == 0), "bad config");
+  static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0 && (NCL == 1 || NV % 256 == 0), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* hL = smem;                                    // [MT][H/16][64][4]
-  float* red = smem + MT * H * 16;                     // [MT][NUG][KS-1][4][64][4]
-  int* s_dead = reinterpret_cast<int*>(smem + MT * H * 16 + RED);
+  // h_{t-1} tile as split bf16 (hi, lo): [MT*16 rows][LDH], one ds_read_b128 per MFMA B operand
+  unsigned short* hiL = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* loL = hiL + MT * 16 * LDH;
+  float* red = smem + MT * 16 * LDH;                   // [MT][NUG][KS-1][4][64][4]
+  int* s_dead = reinterpret_cast<int*>(red + RED);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -144,6 +142,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
   unsigned* flags = a.flags + cl * NCL;
   if (tid == 0) *s_dead = 0;
+  for (int i = tid; i < MT * 16 * LDH; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;   // hi and lo, pad included
   // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
   int vrows = a.B - b0;
   if (vrows > 16 * MT) vrows = 16 * MT;
@@ -151,17 +150,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
 
-  // W_hh fragments (A operand): A[m][k] = W_hh[g*H + uw][k]; MFMA step (kg,i) uses k = kp*KPER + kg*16 + q*4 + i
-  float w[4][KG * 4];
-  if (active) {
+  // W_hh fragments (A operand of v_mfma_f32_16x16x32_bf16), split into bf16 hi/lo, resident for the
+  // whole sequence: A[m][k] = W_hh[g*H + uw][k], k-step s of this lane covers k = kp*KPER + s*32 + q*8 .. +7
+  bf16x8 whi[4][NKS], wlo[4][NKS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int kg = 0; kg < KG; ++kg) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.Whh + (long)(g * H + uw) * H + kp * KPER + kg * 16 + q * 4);
-        w[g][kg * 4 + 0] = v[0]; w[g][kg * 4 + 1] = v[1]; w[g][kg * 4 + 2] = v[2]; w[g][kg * 4 + 3] = v[3];
+    for (int s = 0; s < NKS; ++s) {
+      const int k0 = kp * KPER + s * 32 + q * 8;
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (active && k0 < H) {
+        const float* wp = a.Whh + (long)(g * H + uw) * H + k0;
+        v0 = *reinterpret_cast<const f32x4*>(wp);
+        v1 = *reinterpret_cast<const f32x4*>(wp + 4);
       }
-  }
+      tb_split8(v0, v1, whi[g][s], wlo[g][s]);
+    }
   f32x4 c[MT], pre[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -191,13 +195,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(hL + ((mt * (H / 16) + kp * KG + kg) * 64 + lane) * 4);
+        for (int s = 0; s < NKS; ++s) {
+          const int ho = (mt * 16 + col) * LDH + kp * KPER + s * 32 + q * 8;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hiL + ho));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(loL + ho));
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-              acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g][kg * 4 + i], hv[i], acc[mt][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[mt][g] = tb_mfma_bf16x3(whi[g][s], wlo[g][s], bh, bl, acc[mt][g]);
         }
         if (KS > 1 && kp > 0) {
 #pragma unroll
@@ -231,7 +234,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           hn[r] = og * ftanh(cn);
           st[mt][0][r] = ig; st[mt][1][r] = fg; st[mt][2][r] = gg; st[mt][3][r] = og;
         }
-        *reinterpret_cast<f32x4*>(hL + mt * H * 16 + hl_off(col, u0)) = hn;
+        u32x2 sh, sl;
+        tb_split4(hn, sh, sl);
+        *reinterpret_cast<u32x2*>(hiL + (mt * 16 + col) * LDH + u0) = sh;
+        *reinterpret_cast<u32x2*>(loL + (mt * 16 + col) * LDH + u0) = sl;
         stg4<(NCL > 1 ? kSC1 : 0)>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn);
       }
     }
@@ -325,7 +331,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       for (int n = 0; n < NLD; ++n) {
         const int e = tid + 256 * n;
         const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-        if ((c4 * 4) / US != j) *reinterpret_cast<u32x4*>(hL + mt * H * 16 + hl_off(row, c4 * 4)) = buf[n];
+        if ((c4 * 4) / US != j) {
+          u32x2 sh, sl;
+          tb_split4(__builtin_bit_cast(f32x4, buf[n]), sh, sl);
+          *reinterpret_cast<u32x2*>(hiL + (mt * 16 + row) * LDH + c4 * 4) = sh;
+          *reinterpret_cast<u32x2*>(loL + (mt * 16 + row) * LDH + c4 * 4) = sl;
+        }
       }
     }
     __syncthreads();   // hL complete for step t+1
@@ -361,7 +372,8 @@ template <int H, int US, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int NCL = H / US;
   constexpr int KD = 4 * US;                       // k dimension = this member's gate rows
-  constexpr int KGD = KD / 16;
+  constexpr int NKD = KD / 32;                     // 32-deep MFMA k-steps
+  constexpr int LDG = KD + 8;                      // LDS row stride of the dgates tile (bf16 elements)
   constexpr int NTW = H >= 64 ? H / 64 : 1;        // 16-col output tiles per wave
   constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
   constexpr int QPR = US / 4;                      // unit quads per row
@@ -371,8 +383,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   static_assert((256 % QPR) == 0 && (NE % 256 == 0 || NE < 256), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* dgL = smem;                               // [MT][KD/16][64][4]
-  float* dhL = smem + MT * KD * 16;                // [MT][16][LDH] this member's partial dh_{t-1}
+  // dgates_t of this member as split bf16 (hi, lo): [MT*16 rows][LDG]
+  unsigned short* dgHi = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* dgLo = dgHi + MT * 16 * LDG;
+  float* dhL = smem + MT * 16 * LDG;               // [MT][16][LDH] this member's partial dh_{t-1}
   float* dbL = dhL + MT * 16 * LDH;                // [256][16] bias-grad reduction
   int* s_dead = reinterpret_cast<int*>(dbL + 4096);
 
@@ -394,20 +408,26 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)Xc, 0, NCL > 1 ? 3 * XSLAB * 4 : 0, kBufFlags);
 
-  // W_hh fragments (A operand of the transposed product dh^T = W_hh^T . dgates^T):
-  // A[m][k] = W_hh[grow(k)][n0 + m], k = kg*16 + q*4 + i, grow(k) = (k/US)*H + j*US + k%US
-  float wb[NTW][KGD * 4];
+  // W_hh fragments (A operand of the transposed product dh^T = W_hh^T . dgates^T), split bf16 hi/lo:
+  // A[m][k] = W_hh[grow(k)][n0 + m], k = s*32 + q*8 + i, grow(k) = (k/US)*H + j*US + k%US
+  bf16x8 wbh[NTW][NKD], wbl[NTW][NKD];
   const bool mactive = wave < NAW;
-  if (mactive) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
+  for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-      for (int s = 0; s < KGD * 4; ++s) {
-        const int k = (s >> 2) * 16 + q * 4 + (s & 3);
-        const int grow = (k / US) * H + j * US + (k % US);
-        wb[nt][s] = a.Whh[(long)grow * H + (wave * NTW + nt) * 16 + col];
+    for (int s = 0; s < NKD; ++s) {
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (mactive) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = s * 32 + q * 8 + i;
+          const int grow = (k / US) * H + j * US + (k % US);
+          const float wv = a.Whh[(long)grow * H + (wave * NTW + nt) * 16 + col];
+          if (i < 4) v0[i] = wv; else v1[i - 4] = wv;
+        }
       }
-  }
+      tb_split8(v0, v1, wbh[nt][s], wbl[nt][s]);
+    }
   // elementwise items: e = tid + 256*n -> unit quad qd (constant per thread), row, mt
   const int qd = tid % QPR;
   const int ul0 = qd * 4, uabs0 = j * US + ul0;
@@ -468,11 +488,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         dgv[n][0][r] = di; dgv[n][1][r] = df; dgv[n][2][r] = dg; dgv[n][3][r] = dob;
       }
       if (e < NE) {
-        float* dl = dgL + mt * KD * 16;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           dbacc[g] += dgv[n][g];
-          *reinterpret_cast<f32x4*>(dl + hl_off(row, g * US + ul0)) = dgv[n][g];
+          u32x2 sh, sl;
+          tb_split4(dgv[n][g], sh, sl);
+          *reinterpret_cast<u32x2*>(dgHi + (mt * 16 + row) * LDG + g * US + ul0) = sh;
+          *reinterpret_cast<u32x2*>(dgLo + (mt * 16 + row) * LDG + g * US + ul0) = sl;
         }
       }
     }
@@ -490,13 +512,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) acc[nt] = zero4;
 #pragma unroll
-          for (int kg = 0; kg < KGD; ++kg) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(dgL + ((mt * KGD + kg) * 64 + lane) * 4);
+          for (int s = 0; s < NKD; ++s) {
+            const int go = (mt * 16 + col) * LDG + s * 32 + q * 8;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgHi + go));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgLo + go));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int nt = 0; nt < NTW; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[nt][kg * 4 + i], dv[i], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = tb_mfma_bf16x3(wbh[nt][s], wbl[nt][s], bh, bl, acc[nt]);
           }
           // lane: batch row `col`, output units n0 .. n0+3
 #pragma unroll
@@ -664,7 +685,7 @@ bool make_plan(int H, int B, Plan& p) {
   int US, KS;
   switch (H) {
     case 16: US = 16; KS = 1; break;
-    case 32: US = 32; KS = 2; break;
+    case 32: US = 32; KS = 1; break;
     case 64: US = 64; KS = 1; break;
     case 128: US = 32; KS = 2; break;
     case 256: US = 32; KS = 2; break;
@@ -681,8 +702,9 @@ bool make_plan(int H, int B, Plan& p) {
   p.rows_per_cluster = 16 * MT;
   p.clusters_per_launch = max_clusters;
   const int NUG = US / 16;
-  p.lds_fwd = ((size_t)MT * H * 16 + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
-  p.lds_bwd = ((size_t)MT * 4 * US * 16 + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
+  const int HK = H < 32 ? 32 : H;
+  p.lds_fwd = ((size_t)MT * 16 * (HK + 8) + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
+  p.lds_bwd = ((size_t)MT * 16 * (4 * US + 8) + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
   return true;
 }
 
@@ -719,7 +741,7 @@ int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
 
 int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(16, 16, 1, 1); FWD_CASE(16, 16, 1, 2); FWD_CASE(16, 16, 1, 4);
-  FWD_CASE(32, 32, 2, 1); FWD_CASE(32, 32, 2, 2); FWD_CASE(32, 32, 2, 4);
+  FWD_CASE(32, 32, 1, 1); FWD_CASE(32, 32, 1, 2); FWD_CASE(32, 32, 1, 4);
   FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   FWD_CASE(256, 32, 2, 1); FWD_CASE(256, 32, 2, 2);
