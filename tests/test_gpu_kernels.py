@@ -56,6 +56,8 @@ def test_library_loaded_is_hip():
 @pytest.mark.parametrize("M,K,N,act", [(64, 16, 64, 0), (100, 11, 7, 1), (333, 36, 256, 0), (130, 256, 1, 2),
                                         (48 * 5, 48, 48, 0), (1000, 128, 32, 1), (17, 5, 3, 0)])
 def test_linear_fwd_bwd(dev, M, K, N, act):
+    """GEMM operands are split bf16 hi+lo (2^-17 relative each, lo.lo dropped): a single product is
+    good to ~1.5e-5, sums over k average below that.  north_star's bar is 1e-4 forward / 1e-3 gradients."""
     from timeband_amd import ops
     rng = np.random.default_rng(M + K + N)
     x = rng.uniform(-1, 1, (M, K)).astype(np.float32)
@@ -66,11 +68,11 @@ def test_linear_fwd_bwd(dev, M, K, N, act):
     y_ref = {0: z, 1: np.tanh(z), 2: 1 / (1 + np.exp(-z))}[act]
     xt, Wt, bt = T(x, dev).requires_grad_(), T(W, dev).requires_grad_(), T(b, dev).requires_grad_()
     y = ops.linear_act(xt, Wt, bt, act)
-    assert rel(y.detach().cpu().numpy(), y_ref) < 1e-5
+    assert rel(y.detach().cpu().numpy(), y_ref) < 2e-5
     y.backward(T(dy, dev))
     dz = dy * {0: 1.0, 1: 1 - y_ref ** 2, 2: y_ref * (1 - y_ref)}[act]
-    assert rel(xt.grad.cpu().numpy(), dz @ W.astype(np.float64)) < 1e-5
-    assert rel(Wt.grad.cpu().numpy(), dz.T @ x.astype(np.float64)) < 1e-5
+    assert rel(xt.grad.cpu().numpy(), dz @ W.astype(np.float64)) < 3e-5
+    assert rel(Wt.grad.cpu().numpy(), dz.T @ x.astype(np.float64)) < 3e-5
     assert rel(bt.grad.cpu().numpy(), dz.sum(0)) < 1e-5
 
 

@@ -1,4 +1,4 @@
-// K1: fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 fma chain).
+// K1: fp32-grade GEMM on the gfx950 matrix cores with split-precision bf16 operands ("bf16x3").
 //
 // Replaces the library ops the reference reaches through torch: the LSTM input projection
 // x.W_ih^T (aten::lstm, reference source/utils/lstm_layer.py:31-33,44-46,75,83), nn.Linear
@@ -10,20 +10,24 @@
 // LAY_A = 0: A stored [M][K] (k contiguous).   LAY_A = 1: A stored [K][M] (m contiguous).
 // LAY_B = 0: B stored [N][K] (k contiguous).   LAY_B = 1: B stored [K][N] (n contiguous).
 //
-// Block tile BM x BN x 16 with 4 waves laid out WGM x WGN, each wave a (BM/WGM) x (BN/WGN) patch of
-// 16x16 MFMA tiles (128x128 as 2x2 waves of 4x4 tiles for wide outputs; 256x64 / 256x32 as 4x1 for
-// the narrow ones), 32 flop per staged byte.  Operand tiles keep their global orientation in LDS
-// (no transposing stores): a k-contiguous tile is [rows][16+4] and one ds_read_b128 per lane yields
-// the operand of 4 k-steps, an m-contiguous tile is [16][rows+4] read with 4 ds_read_b32; both use
-// the k order k = (lane>>4)*4 + step, so any layout pair multiplies correctly.  Two LDS stages, one
-// barrier per k-tile, next tile's global loads in flight under the MFMAs.
+// Operands stay fp32 in HBM.  Each fp32 tile is split in registers into bf16 hi + bf16 lo
+// (common.h) on its way into LDS, and every 16x16x32 product is three v_mfma_f32_16x16x32_bf16
+// (hi.hi + hi.lo + lo.hi, fp32 accumulate): ~2^-17 relative operand error, i.e. fp32-grade results,
+// at 16/3 of the fp32 MFMA rate -- which moves these GEMMs (K <= 128 projections, K = B.T weight
+// gradients over a 268 MB dgates matrix) from MFMA-bound to HBM-bound.
+// Block tile BM x BN x 32 with 4 waves laid out WGM x WGN, each wave a (BM/WGM) x (BN/WGN) patch of
+// 16x16 MFMA tiles.  Tiles keep their global orientation in LDS (no transposing stores, 8-byte
+// ds_writes): a k-contiguous tile is [rows][32+8] and one ds_read_b128 per lane is an MFMA operand;
+// an m-contiguous tile is [32][rows+8] and the operand is two ds_read_b64_tr_b16 (the gfx950
+// hardware transpose read).  Next tile's global loads fly under the MFMAs.
 // Split-K (gridDim.z) writes partial slabs that splitk_reduce sums in a fixed order (bitwise
 // reproducible; no float atomics).
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   const float* A;
@@ -42,16 +46,16 @@ struct GemmArgs {
 
 template <int LAY, int ROWS>
 struct Tile {
-  static constexpr int LD = LAY == 0 ? BK + 4 : ROWS + 4;            // LDS row stride (floats)
-  static constexpr int FLOATS = LAY == 0 ? ROWS * LD : BK * LD;      // one stage
-  static constexpr int NCHUNK = ROWS * BK / 4;                       // 16-byte chunks of one stage
+  static constexpr int LD = LAY == 0 ? BK + 8 : ROWS + 8;            // LDS row stride (bf16 elements)
+  static constexpr int ELEMS = LAY == 0 ? ROWS * LD : BK * LD;       // one image (hi or lo)
+  static constexpr int NCHUNK = ROWS * BK / 4;                       // 16-byte fp32 chunks of one tile
   static constexpr int NCH = (NCHUNK + 255) / 256;                   // chunks per thread
   static_assert(NCHUNK % 256 == 0 || NCHUNK < 256, "chunk count must tile the block");
 
   // chunk c of this thread -> (row, k) of its first element
   static __device__ __forceinline__ void where(int c, int& r, int& k) {
     const int e = threadIdx.x + 256 * c;
-    if (LAY == 0) { r = e >> 2; k = (e & 3) * 4; }
+    if (LAY == 0) { r = e >> 3; k = (e & 7) * 4; }
     else { k = e / (ROWS / 4); r = (e % (ROWS / 4)) * 4; }
   }
 
@@ -93,35 +97,43 @@ struct Tile {
     }
   }
 
-  static __device__ __forceinline__ void store(float* sm, const f32x4 (&v)[NCH]) {
+  // split into bf16 hi / lo and store in the global orientation (8-byte LDS writes)
+  static __device__ __forceinline__ void store(unsigned short* hi, unsigned short* lo, const f32x4 (&v)[NCH]) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       int r, k;
       where(c, r, k);
       if (NCHUNK < 256 && threadIdx.x >= NCHUNK) continue;
-      if (LAY == 0) *reinterpret_cast<f32x4*>(sm + r * LD + k) = v[c];
-      else *reinterpret_cast<f32x4*>(sm + k * LD + r) = v[c];
+      u32x2 sh, sl;
+      tb_split4(v[c], sh, sl);
+      const int off = LAY == 0 ? r * LD + k : k * LD + r;
+      *reinterpret_cast<u32x2*>(hi + off) = sh;
+      *reinterpret_cast<u32x2*>(lo + off) = sl;
     }
   }
 
-  // MFMA operand of the 16 rows starting at `row`, for the 4 k-steps of one k-tile
-  static __device__ __forceinline__ f32x4 frag(const float* sm, int row, int col, int q) {
-    if (LAY == 0) return *reinterpret_cast<const f32x4*>(sm + (row + col) * LD + q * 4);
-    f32x4 f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) f[i] = sm[(q * 4 + i) * LD + row + col];
-    return f;
+  // MFMA operand (8 consecutive k of row `row + col`, k = q*8 ..) from one image
+  static __device__ __forceinline__ bf16x8 frag(const unsigned short* img, int row, int col, int q) {
+    if (LAY == 0) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (row + col) * LD + q * 8));
+    // [k][row] image: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row block;
+    // lane 4*qq+p of the group supplies the address of block row qq, columns 4p..4p+3
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const unsigned short* p0 = img + (q * 8 + (col >> 2)) * LD + row + 4 * (col & 3);
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * LD));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    return __builtin_bit_cast(bf16x8, (u32x4){ua[0], ua[1], ub[0], ub[1]});
   }
 };
 
 template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   using TA = Tile<LAY_A, BM>;
   using TB = Tile<LAY_B, BN>;
   constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;
   static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad wave layout");
-  __shared__ __attribute__((aligned(16))) float As[2][TA::FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][TB::FLOATS];
+  __shared__ __attribute__((aligned(16))) unsigned short Ah[TA::ELEMS], Al[TA::ELEMS];
+  __shared__ __attribute__((aligned(16))) unsigned short Bh[TB::ELEMS], Bl[TB::ELEMS];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
   const int kbeg = z * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
@@ -139,35 +151,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs a) {
   if (kbeg < kend) {
     TA::load(a.A, a.lda, m0, a.M, kbeg, kend, a.vecA, 0, 1, ra);
     TB::load(a.B, a.ldb, n0, a.N, kbeg, kend, a.vecB, a.b_shift, a.b_period, rb);
-    TA::store(As[0], ra);
-    TB::store(Bs[0], rb);
   }
-  __syncthreads();
-  int st = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {   // next tile's global loads fly under this tile's MFMAs
+    TA::store(Ah, Al, ra);
+    TB::store(Bh, Bl, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {   // next tile's global loads fly under this tile's MFMAs
       TA::load(a.A, a.lda, m0, a.M, k0 + BK, kend, a.vecA, 0, 1, ra);
       TB::load(a.B, a.ldb, n0, a.N, k0 + BK, kend, a.vecB, a.b_shift, a.b_period, rb);
     }
-    f32x4 af[TM], bf[TN];
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = TA::frag(As[st], (wm * TM + i) * 16, col, q);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = TB::frag(Bs[st], (wn * TN + j) * 16, col, q);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-    if (more) {
-      TA::store(As[st ^ 1], ra);
-      TB::store(Bs[st ^ 1], rb);
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = TA::frag(Ah, (wm * TM + i) * 16, col, q);
+      al[i] = TA::frag(Al, (wm * TM + i) * 16, col, q);
     }
-    __syncthreads();
-    st ^= 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
+      bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = tb_mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+    __syncthreads();   // all fragment reads done before the next tile overwrites the images
   }
 
   float* out = a.splits > 1 ? a.slab + (size_t)z * a.M * a.N : a.C;
@@ -210,10 +218,10 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
 
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
-  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<1, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
 }
 
 }  // namespace
@@ -241,9 +249,9 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   const long tiles = (long)mt * nt;
   int splits = 1;
   const int cus = tb_num_cus();
-  if (tiles < cus && K >= 64 * BK && ws) {
+  if (tiles < cus && K >= 32 * BK && ws) {
     splits = (int)((2L * cus + tiles - 1) / tiles);
-    const int maxs = K / (16 * BK);
+    const int maxs = K / (8 * BK);
     if (splits > maxs) splits = maxs;
     if (splits > 64) splits = 64;
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
@@ -260,7 +268,7 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   if (cfg == 0) launch_cfg<256, 32, 4, 1>(a, transA, transB, grid, stream);
   else if (cfg == 1) launch_cfg<256, 64, 4, 1>(a, transA, transB, grid, stream);
   else launch_cfg<128, 128, 2, 2>(a, transA, transB, grid, stream);
-  TB_LAUNCH_CHECK("gemm_f32_kernel");
+  TB_LAUNCH_CHECK("gemm_bf16x3_kernel");
   if (splits > 1) {
     const long total = (long)M * N;
     int blocks = (int)((total + 255) / 256);
