@@ -186,6 +186,26 @@ def test_forward_golden(dev, name):
     assert rel(DGx.cpu().numpy(), z["fwd.DGx"]) < 1e-4
 
 
+def test_discriminator_pair_matches_separate(dev):
+    """netD.pair(real, fake) (one 2B-row launch) == (netD(real), netD(fake)), values and gradients."""
+    z = np.load(os.path.join(GOLDEN, "scenario_uneven.npz"))
+    netD, netG = build_nets(z, dev)
+    y = T(z["y"], dev)
+    fake = netG(T(z["x"], dev)).detach().requires_grad_()
+    Dy, DGx = netD.pair(y, fake)
+    (Dy.sum() - 2 * DGx.sum()).backward()
+    got = {k: p.grad.clone() for k, p in netD.named_parameters()}
+    gfake = fake.grad.clone()
+    netD.zero_grad()
+    fake.grad = None
+    Dy2, DGx2 = netD(y), netD(fake)
+    (Dy2.sum() - 2 * DGx2.sum()).backward()
+    assert torch.equal(Dy, Dy2) and torch.equal(DGx, DGx2)
+    assert rel(gfake.cpu().numpy(), fake.grad.cpu().numpy()) < 1e-6
+    for k, p in netD.named_parameters():
+        assert rel(got[k].cpu().numpy(), p.grad.cpu().numpy()) < 1e-5, k
+
+
 def grads_close(module, want, tol, what):
     gmax = max(np.abs(v).max() for v in want.values())
     for k, p in module.named_parameters():

@@ -94,7 +94,7 @@ class TIMEBANDTrainer:
         with torch.no_grad():
             fake_y = netG(true_x)
         self._critic_opt.zero_grad()
-        Dy, DGx = netD(true_y), netD(fake_y)
+        Dy, DGx = netD.pair(true_y, fake_y)
         errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx, critic=True)
         errD.backward()
         self._critic_opt.all_reduce_grads()
@@ -135,7 +135,7 @@ class TIMEBANDTrainer:
         # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
         with torch.set_grad_enabled(training):
             fake_y = netG(true_x)
-            Dy, DGx = netD(true_y), netD(fake_y)
+            Dy, DGx = netD.pair(true_y, fake_y)
             errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx)
         if training:
             errD.backward()

@@ -78,3 +78,14 @@ class LSTMDiscriminator(nn.Module):
         lin = self.linear[0]
         out = ops.linear_act(r.view(B * T, self.hidden_dim), lin.weight, lin.bias, ops.ACT_SIGMOID)
         return out.view(B, T, 1)
+
+    def pair(self, real, fake):
+        """(netD(real), netD(fake)) of trainer.py:149-150,174-175 as ONE pass over the 2B rows: the rows
+        of a batch are independent through D, so the results are the same, but the persistent
+        recurrent kernels are latency-bound per timestep and run 2B rows in little more than the time
+        of B (and the weight-gradient GEMMs run once over both halves)."""
+        if real.shape != fake.shape:
+            return self(real), self(fake)
+        out = self(torch.cat([real, fake], 0))
+        Dy, DGx = out.view(2, real.size(0), real.size(1), 1).unbind(0)
+        return Dy, DGx

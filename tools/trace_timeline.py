@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Timeline of the LAST step in a rocprofv3 kernel_trace.csv: one line per dispatch with its start
+offset, duration, gap to the previous kernel and grid -- to see per-shape GEMM times and idle gaps.
+usage: python tools/trace_timeline.py kernel_trace.csv [nsteps] [--agg]"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+nsteps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 6
+# a step starts at each window_gather_kernel that follows an adam kernel; simpler: split at window_gather with grid of the big batch
+idx = [i for i, r in enumerate(rows) if "window_gather" in r["Kernel_Name"]]
+# two gathers per step (critic batch + main batch): steps begin at every second gather
+starts = idx[::2]
+lo = starts[-2] if len(starts) >= 2 else 0
+hi = starts[-1] if len(starts) >= 2 else len(rows)
+seg = rows[lo:hi]
+t0 = int(seg[0]["Start_Timestamp"])
+prev_end = t0
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)
+    return n[:58]
+
+
+agg = defaultdict(lambda: [0, 0])
+busy = 0
+for r in seg:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    key = (short(r["Kernel_Name"]), r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""), r.get("Grid_Size_Y", ""), r.get("Grid_Size_Z", ""))
+    agg[key][0] += 1
+    agg[key][1] += e - s
+    busy += e - s
+    if "--agg" not in sys.argv:
+        print(f"{(s - t0) / 1e3:9.1f}us +{(e - s) / 1e3:8.1f}us gap{(s - prev_end) / 1e3:7.1f} {key[0]} grid={key[1]},{key[2]},{key[3]}")
+    prev_end = max(prev_end, e)
+span = int(seg[-1]["End_Timestamp"]) - t0
+print(f"step span {span / 1e6:.3f} ms, kernel busy {busy / 1e6:.3f} ms, {len(seg)} dispatches")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{v[1] / 1e3:9.1f}us n={v[0]:3d} avg={v[1] / v[0] / 1e3:8.1f}us {k[0]} grid={k[1]},{k[2]},{k[3]}")
