@@ -34,11 +34,18 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, jobs=5):
+def build(force=False, verbose=True, jobs=5, stamps=False):
+    """stamps=True: diagnostic build with in-kernel cycle stamps (libtimeband_hip_stamps.so, tools only)."""
+    if stamps:
+        return _build(os.path.join(HERE, "build_stamps"), os.path.join(HERE, "libtimeband_hip_stamps.so"),
+                      FLAGS + ["-DTB_STAMPS"] + os.environ.get("TB_EXTRA_FLAGS", "").split(), verbose, jobs)
     if not force and not needs_build():
         return LIB
+    return _build(os.path.join(HERE, "build"), LIB, FLAGS + os.environ.get("TB_EXTRA_FLAGS", "").split(), verbose, jobs)
+
+
+def _build(objdir, LIB, FLAGS, verbose, jobs):
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     objs = []
@@ -70,5 +77,4 @@ def _drain(procs):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))

@@ -171,10 +171,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
       bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
       bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
     }
+    // three passes over the independent accumulators: no MFMA waits on the one before it
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = tb_mfma_bf16x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     __syncthreads();   // all fragment reads done before the next tile overwrites the images
   }
 

@@ -15,24 +15,58 @@
 // Persistent kernel layout.  The batch is cut into tiles of 16*MT rows; a CLUSTER of NCL = H/US
 // workgroups (one per CU, all co-resident: grid <= #CUs) owns one tile.  Member j owns hidden
 // units [j*US, (j+1)*US): in forward the 4*US rows of W_hh that produce its gates, held in
-// VGPRs for the whole sequence as MFMA A-operand fragments (W_hh never leaves the register file
-// between timesteps); c stays in registers too.  The products are computed TRANSPOSED
-// (gates^T = W_hh . h^T), so a lane's four accumulator registers are four consecutive hidden
-// units of one batch row: every global access of the step (pre-activations, stash, y, the
-// exchange) is a 16-byte access, and the write-through (sc1) exchange stores -- one fabric write
-// each whatever their width -- are 4x fewer than with 4-byte stores.
-// Each timestep every member needs the whole h_{t-1} tile: members write their h slice to
-// y[b,t,:] with sc1 stores, raise a per-member step counter, poll the other members' counters
-// (bounded spin) and read the other slices with L1-bypassing (sc1) loads -- the Guideline-16
-// protocol of cdna_hip_programming.md.  In backward the same W_hh rows produce this member's
-// partial of dh_{t-1} = dgates_t.W_hh; the partials are exchanged reduce-scatter style through a
-// double-buffered slab.  NCL == 1 (H <= 64) needs no global exchange at all.
+// VGPRs for the whole sequence as MFMA A-operand fragments, split into bf16 hi + lo (common.h:
+// three v_mfma_f32_16x16x32_bf16 per product, fp32-grade); c stays in registers too.  The products
+// are computed TRANSPOSED (gates^T = W_hh . h^T), so a lane's four accumulator registers are four
+// consecutive hidden units of one batch row and every global access of the step is 16 bytes wide.
+//
+// Exchange.  Each timestep every member needs the whole h_{t-1} tile (forward: all-gather) or the
+// sum of all members' partials of dh_{t-1} (backward: reduce-scatter).  Both go through a small ring
+// of three slots per cluster in the workspace (hot in L2, one TLB page) that is armed with an
+// all-ones sentinel: every word of a slot is written once per turn, so the data is its own ready
+// flag -- no counters, no store drain.  Forward: the member's finishing waves store their h slice to
+// the ring (and to y for the next layer), the other waves -- which have no memory traffic of their
+// own queued -- poll one piece per storing wave and then pull the other members' slices straight
+// into the LDS h tile; the producer re-arms its slice two steps later (when every consumer has
+// provably read it) and waits for that store before it publishes again.  Backward: the consumer
+// re-arms what it has summed.  At start-up the members exchange the id of the XCD they run on
+// (cluster_hello): when they share one -- the round-robin placement the block->cluster map aims
+// for -- they share an L2 and the exchange uses PLAIN stores that stay there (measured: hand-off
+// 0.6 us instead of 1.8 us, tools/micro/exchange_bench.hip); otherwise it uses write-through
+// (sc1) stores, valid under any placement.  Loads of exchanged data are always L1-bypassing (sc1).
+// All spins are bounded (2 s) and report through the caller's err word.  NCL == 1 (H <= 64) needs
+// no global exchange at all.
 #include "common.h"
 #include <stdlib.h>
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
                    float* ws, size_t ws_bytes, hipStream_t stream);
+
+#ifdef TB_STAMPS
+// Diagnostic build only (tools/lstm_stamps.py): per-segment cycle sums of one workgroup's step loop.
+__device__ unsigned long long tb_stamps[2][4][12];
+#define STAMP_DECL unsigned long long stamp_prev, stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory")
+#define STAMP(i)                                                                          \
+  do {                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    unsigned long long _t;                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");            \
+    stamp_acc[i] += _t - stamp_prev;                                                      \
+    stamp_prev = _t;                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+#define STAMP_FLUSH(k, cl, j)                                                             \
+  do {                                                                                    \
+    if ((cl) == 0 && (j) == 0 && (threadIdx.x & 63) == 0)                                 \
+      for (int _i = 0; _i < 12; ++_i) tb_stamps[k][threadIdx.x >> 6][_i] = stamp_acc[_i]; \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(k, cl, j)
+#endif
 
 namespace {
 
@@ -45,18 +79,19 @@ struct FwdArgs {
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
-  unsigned* flags;     // [nclusters][NCL] step counters, zeroed before launch
+  float* ring;         // [nclusters][3][MT*16][H] exchange ring (NCL > 1), sentinel-armed before the launch
+  unsigned* hello;     // [nclusters][NCL] start-up handshake words, sentinel-armed before the launch
   int* err;            // [4] sticky error words
   int B, T;
   int b_begin;         // first batch row of this launch
   int nclusters;
   int train;
-  int mode;            // bit 0: y is sentinel-armed and is its own ready flag (no drain, no counter)
   unsigned long long timeout_ticks;
 };
 
 // cluster/member decode: keep the members of a cluster on blocks with equal (blockIdx % 8), i.e.
-// on one XCD under the observed round-robin placement (speed only; correctness never depends on it)
+// on one XCD under the observed round-robin placement (speed only; correctness never depends on it:
+// cluster_hello() checks the placement at run time)
 __device__ __forceinline__ void cluster_decode(int NCL, int& cl, int& j) {
   const int G = gridDim.x, b = blockIdx.x;
   if ((G & 7) == 0 && ((G >> 3) % NCL) == 0) {
@@ -69,30 +104,44 @@ __device__ __forceinline__ void cluster_decode(int NCL, int& cl, int& j) {
   }
 }
 
-// Wait until every other member's counter reaches `target`.  Returns false on timeout.
-__device__ __forceinline__ bool wait_members(const unsigned* flags, int NCL, int j, unsigned target,
-                                             unsigned long long timeout, int* err, int* s_dead) {
-  const int lane = threadIdx.x & 63;
+// Start-up handshake of a cluster.  Every member publishes the id of the XCD it runs on with a
+// write-through (sc1) store and reads the others' (sc1 loads work across XCDs).  Returns 1 if ALL
+// members share one XCD -- then they share one L2, and the per-step exchange may use plain stores
+// (which stay in that L2: a third of the hand-off latency of write-through stores) --, 0 if not
+// (the exchange then uses write-through stores, valid under any placement), -1 on timeout.
+// "all equal" is symmetric, so every member takes the same decision.
+__device__ __forceinline__ int cluster_hello(unsigned* hello, int NCL, int j, unsigned long long timeout, int* err,
+                                             int* s_word) {
+  unsigned myx;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(myx));
+  myx &= 0xFu;
+  if (threadIdx.x == 0) tb_store_agent_u32(hello + j, myx);
   if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    unsigned v = myx;
     bool ok = true;
-    if (lane < NCL && lane != j) {
+    for (int m = lane; m < NCL; m += 64) {
       const unsigned long long t0 = wall_clock64();
       unsigned it = 0;
-      while (tb_load_agent_u32(flags + lane) < target) {
-        __builtin_amdgcn_s_sleep(1);
+      unsigned w;
+      while ((w = tb_load_agent_u32(hello + m)) == 0xFFFFFFFFu) {
+        __builtin_amdgcn_s_sleep(2);
         if ((++it & 1023u) == 0 && wall_clock64() - t0 > timeout) {
           ok = false;
           break;
         }
       }
+      if (w != myx) v = 0xFFFFFFF0u;
     }
-    if (!ok) {
-      atomicExch(err, 1);
-      *s_dead = 1;
+    const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+    const bool all_eq = __builtin_amdgcn_ballot_w64(v != myx) == 0ull;
+    if (lane == 0) {
+      if (!all_ok) atomicExch(err, 1);
+      *s_word = all_ok ? (all_eq ? 1 : 0) : -1;
     }
   }
   __syncthreads();
-  return *s_dead == 0;
+  return *s_word;
 }
 
 __device__ __forceinline__ float fsig(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -106,6 +155,14 @@ template <int AUX>
 __device__ __forceinline__ void stg4(__amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(float_off * 4), 0, AUX);
 }
+// exchange store: plain when the cluster shares one L2, write-through otherwise
+__device__ __forceinline__ void stx4(bool same_l2, __amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
+  if (same_l2) stg4<0>(r, float_off, v);
+  else stg4<kSC1>(r, float_off, v);
+}
+__device__ __forceinline__ bool armed(u32x4 v) {
+  return v[0] == kSentinel || v[1] == kSentinel || v[2] == kSentinel || v[3] == kSentinel;
+}
 
 template <int H, int US, int KS, int MT>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
@@ -117,9 +174,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int LDH = HK + 8;           // LDS row stride of the h tile (bf16 elements; 16-byte pad)
   constexpr int NACT = NUG * KS;        // waves doing MFMA work
   constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
-  constexpr int NV = MT * 16 * (H / 4); // 16-byte pieces of the whole h tile
-  constexpr int NLD = (NV + 255) / 256;
-  static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0 && (NCL == 1 || NV % 256 == 0), "bad config");
+  // exchange (NCL > 1): waves [0, NUG) finish the gates and publish, waves [NUG, 4) pull
+  constexpr int NPW = NCL > 1 ? 4 - NUG : 1;            // puller waves
+  constexpr int NPP = (NCL + NPW - 1) / NPW;            // producers per puller wave
+  constexpr int LPP = MT * 16 * (US / 4) / 64;          // 16-byte loads per lane per producer
+  constexpr int NLD = NPP * LPP;                        // loads per lane per step
+  constexpr int RS = MT * 16 * H;                       // floats per ring slot
+  static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0, "bad config");
+  static_assert(NCL == 1 || (NUG < 4 && (MT * 16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // h_{t-1} tile as split bf16 (hi, lo): [MT*16 rows][LDH], one ds_read_b128 per MFMA B operand
@@ -127,6 +189,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   unsigned short* loL = hiL + MT * 16 * LDH;
   float* red = smem + MT * 16 * LDH;                   // [MT][NUG][KS-1][4][64][4]
   int* s_dead = reinterpret_cast<int*>(red + RED);
+  int* s_word = s_dead + 1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -140,7 +203,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
-  unsigned* flags = a.flags + cl * NCL;
   if (tid == 0) *s_dead = 0;
   for (int i = tid; i < MT * 16 * LDH; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;   // hi and lo, pad included
   // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
@@ -149,6 +211,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (long)b0 * rowP), 0, (int)(vrows * rowP * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(NCL > 1 ? a.ring + (size_t)cl * 3 * RS : a.y), 0, NCL > 1 ? 3 * RS * 4 : 0, kBufFlags);
 
   // W_hh fragments (A operand of v_mfma_f32_16x16x32_bf16), split into bf16 hi/lo, resident for the
   // whole sequence: A[m][k] = W_hh[g*H + uw][k], k-step s of this lane covers k = kp*KPER + s*32 + q*8 .. +7
@@ -174,10 +237,33 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     for (int g = 0; g < 4; ++g)
       pre[mt][g] = fin ? ldg4<0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  __syncthreads();
+  bool same_l2 = false;
+  if (NCL > 1) {
+    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, NCL, j, a.timeout_ticks, a.err, s_word);   // has a barrier
+    if (hs < 0) return;
+    same_l2 = hs == 1;
+  } else {
+    __syncthreads();
+  }
 
+  STAMP_DECL;
+#ifdef TB_STAMPS
+  stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
+  { unsigned xx; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xx)); stamp_acc[11] = (unsigned long long)xx * T; }
+#endif
   for (int t = 0; t < T; ++t) {
-    // (A) next step's pre-activations: independent of the recurrence, in flight under this step
+    STAMP(0);
+    const bool exchange = NCL > 1 && t + 1 < T;
+    // (A) every consumer has read h_{t-2} (it published h_{t-1} after that, and the pull of h_{t-1} is
+    // complete): re-arm this member's slice of that slot, which is written next at step t+1
+    if (NCL > 1 && fin && t >= 2) {
+      const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
+    }
+    // next step's pre-activations: independent of the recurrence.  Issued HERE, where no hand-off load of
+    // this CU is pending for the next ~3000 cycles: loads return in order per CU, so an HBM miss issued
+    // just before the polls would hold every poll and pull behind it (measured: +2000 cycles per step)
     f32x4 nxt[MT][4];
     if (t + 1 < T && fin) {
 #pragma unroll
@@ -199,8 +285,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           const int ho = (mt * 16 + col) * LDH + kp * KPER + s * 32 + q * 8;
           const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hiL + ho));
           const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(loL + ho));
+          // three passes over the four independent accumulators: no MFMA waits on the one before it
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[mt][g] = tb_mfma_bf16x3(whi[g][s], wlo[g][s], bh, bl, acc[mt][g]);
+          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bl, acc[mt][g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][s], bh, acc[mt][g], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc[mt][g], 0, 0, 0);
         }
         if (KS > 1 && kp > 0) {
 #pragma unroll
@@ -209,10 +300,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         }
       }
     }
-    __syncthreads();   // all reads of hL done; k-split partials visible
-    // (C) gate math, state update, h into LDS and y -- 4 consecutive units of one batch row per lane
-    f32x4 st[MT][4];
+    STAMP(1);
+    __syncthreads();   // all reads of the h tile done; k-split partials visible
+    STAMP(2);
     if (fin) {
+      // (C) gate math, state update, h into LDS, the ring and y -- 4 consecutive units of one batch row per lane
+      f32x4 st[MT][4], hn[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 z[4];
@@ -225,101 +318,64 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
               z[g] += *reinterpret_cast<const f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
           }
         }
-        f32x4 hn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float ig = fsig(z[0][r]), fg = fsig(z[1][r]), gg = ftanh(z[2][r]), og = fsig(z[3][r]);
           const float cn = fg * c[mt][r] + ig * gg;
           c[mt][r] = cn;
-          hn[r] = og * ftanh(cn);
+          hn[mt][r] = og * ftanh(cn);
           st[mt][0][r] = ig; st[mt][1][r] = fg; st[mt][2][r] = gg; st[mt][3][r] = og;
         }
         u32x2 sh, sl;
-        tb_split4(hn, sh, sl);
+        tb_split4(hn[mt], sh, sl);
         *reinterpret_cast<u32x2*>(hiL + (mt * 16 + col) * LDH + u0) = sh;
         *reinterpret_cast<u32x2*>(loL + (mt * 16 + col) * LDH + u0) = sl;
-        stg4<(NCL > 1 ? kSC1 : 0)>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn);
       }
-    }
-    const bool exchange = NCL > 1 && t + 1 < T;
-    const bool dataflag = (a.mode & 1) != 0;
-    if (exchange && !dataflag) {
-      // publish this member's h slice: drain ONLY the y stores (the stash stores come after the flag)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(t + 1));
-      asm volatile("" ::: "memory");
-    }
-    if (a.train && fin) {   // BPTT stash: activated gates over P in place, cell state
+      if (exchange) {
+        // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
+        // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
+        // of a wave complete in order: all but the 4*MT prefetch loads issued after the re-arm.
+        STAMP(5);
+        if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (MT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        STAMP(6);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[mt][g]);
-        stg4<0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, c[mt]);
+        for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hn[mt]);
       }
-    }
-    if (exchange) {
-      u32x4 buf[NLD];
-      if (!dataflag) {
-        if (!wait_members(flags, NCL, j, (unsigned)(t + 1), a.timeout_ticks, a.err, s_dead)) break;
-        // pull the whole tile (own slice included: one predicate-free burst) with L1-bypassing loads
 #pragma unroll
-        for (int n = 0; n < NLD; ++n) {
-          const int e = tid + 256 * n;
-          const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-          buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rY, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, kSC1);
+      for (int mt = 0; mt < MT; ++mt) stg4<0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn[mt]);
+      STAMP(3);
+      if (a.train) {   // BPTT stash: activated gates over P in place, cell state
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[mt][g]);
+          stg4<0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, c[mt]);
         }
-      } else {
-        // y was armed with the sentinel before the launch and every (b,t,u) is written exactly once,
-        // so the data is its own ready flag.  One idle wave polls one piece per member first (cheap
-        // on the fabric), then everyone pulls the tile and re-polls only pieces still armed.
-        if (wave == 3) {
-          if (lane < NCL && lane != j) {
-            const int voff = (int)(((long)(vrows - 1) * rowY + (long)t * H + lane * US + US - 4) * 4);
-            const unsigned long long t0 = wall_clock64();
-            unsigned it = 0;
-            while (true) {
-              const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rY, voff, 0, kSC1);
-              if (v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel) break;
-              __builtin_amdgcn_s_sleep(1);
-              if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
-                atomicExch(a.err, 1);
-                *s_dead = 1;
-                break;
-              }
-            }
-          }
-        }
-        __syncthreads();
-        if (*s_dead) break;
-        unsigned pend = 0;
+      }
+      STAMP(4);
 #pragma unroll
-        for (int n = 0; n < NLD; ++n) {
-          const int e = tid + 256 * n;
-          const int c4 = (e >> 4) % (H / 4);
-          if ((c4 * 4) / US != j) pend |= 1u << n;
-        }
-        bool first = true;
-        unsigned it = 0;
-        unsigned long long t0 = 0;
-        while (pend) {
-          asm volatile("" ::: "memory");
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int n = 0; n < NLD; ++n) {
-            const int e = tid + 256 * n;
-            const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-            if (first || ((pend >> n) & 1u))
-              buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rY, (int)(((long)(mt * 16 + row) * rowY + (long)t * H + c4 * 4) * 4), 0, kSC1);
-          }
-          first = false;
-#pragma unroll
-          for (int n = 0; n < NLD; ++n)
-            if (buf[n][0] != kSentinel && buf[n][1] != kSentinel && buf[n][2] != kSentinel && buf[n][3] != kSentinel)
-              pend &= ~(1u << n);
-          if (pend && (++it & 255u) == 0) {
-            const unsigned long long now = wall_clock64();
-            if (t0 == 0) t0 = now;
-            else if (now - t0 > a.timeout_ticks) {
+        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[mt][g];
+    } else if (exchange) {
+      // (D) puller waves: the other members' slices of h_t from the ring into the LDS tile.  The ring is
+      // sentinel-armed and every slot word is written once per turn, so the data is its own ready flag:
+      // poll the last piece each storing wave of each of my producers writes, then pull, then re-pull
+      // whatever is still armed.  These waves issue no other memory traffic, so nothing queues before
+      // the hand-off in their memory counters.
+      const int pw = wave - NUG;
+      const long sbase = (long)(t % 3) * RS;
+      if (lane < NPP * NUG) {
+        const int m = pw + (lane / NUG) * NPW;
+        if (m < NCL && m != j) {
+          const int voff = (int)((sbase + (long)(MT * 16 - 1) * H + m * US + (lane % NUG) * 16 + 12) * 4);
+          const unsigned long long t0 = wall_clock64();
+          unsigned it = 0;
+          while (armed(__builtin_amdgcn_raw_buffer_load_b128(rR, voff, 0, kSC1))) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
               atomicExch(a.err, 1);
               *s_dead = 1;
               break;
@@ -327,27 +383,56 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           }
         }
       }
+      STAMP(5);
+      u32x4 buf[NLD];
+      unsigned pend = 0;
 #pragma unroll
       for (int n = 0; n < NLD; ++n) {
-        const int e = tid + 256 * n;
-        const int row = e & 15, c4 = (e >> 4) % (H / 4), mt = e / (16 * (H / 4));
-        if ((c4 * 4) / US != j) {
+        const int m = pw + (n / LPP) * NPW;
+        if (m < NCL && m != j) pend |= 1u << n;
+      }
+      unsigned it = 0;
+      unsigned long long t0 = 0;
+      while (pend) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+          const int m = pw + (n / LPP) * NPW;
+          const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
+          if ((pend >> n) & 1u) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
+        }
+#pragma unroll
+        for (int n = 0; n < NLD; ++n)
+          if (((pend >> n) & 1u) && !armed(buf[n])) pend &= ~(1u << n);
+        if (pend && (++it & 255u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > a.timeout_ticks) {
+            atomicExch(a.err, 1);
+            *s_dead = 1;
+            break;
+          }
+        }
+      }
+      STAMP(7);
+#pragma unroll
+      for (int n = 0; n < NLD; ++n) {
+        const int m = pw + (n / LPP) * NPW;
+        const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
+        if (m < NCL && m != j) {
           u32x2 sh, sl;
           tb_split4(__builtin_bit_cast(f32x4, buf[n]), sh, sl);
-          *reinterpret_cast<u32x2*>(hiL + (mt * 16 + row) * LDH + c4 * 4) = sh;
-          *reinterpret_cast<u32x2*>(loL + (mt * 16 + row) * LDH + c4 * 4) = sl;
+          *reinterpret_cast<u32x2*>(hiL + row * LDH + m * US + c4 * 4) = sh;
+          *reinterpret_cast<u32x2*>(loL + row * LDH + m * US + c4 * 4) = sl;
         }
       }
     }
-    __syncthreads();   // hL complete for step t+1
+    STAMP(8);
+    __syncthreads();   // h tile complete for step t+1
+    STAMP(9);
     if (NCL > 1 && *s_dead) break;
-    if (t + 1 < T) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[mt][g];
-    }
   }
+  STAMP_FLUSH(0, cl, j);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -358,13 +443,12 @@ struct BwdArgs {
   const float* Whh;    // [4H][H]
   float* X;            // [nclusters][3][NCL consumers][NCL producers][MT*16][US] exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
-  unsigned* flags;
+  unsigned* hello;     // [nclusters][NCL] start-up handshake words, sentinel-armed before the launch
   int* err;
   int B, T;
   int b_begin;
   int cl_begin;        // index of this launch's first cluster in dbpart
   int nclusters;
-  int mode;
   unsigned long long timeout_ticks;
 };
 
@@ -389,6 +473,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   float* dhL = smem + MT * 16 * LDG;               // [MT][16][LDH] this member's partial dh_{t-1}
   float* dbL = dhL + MT * 16 * LDH;                // [256][16] bias-grad reduction
   int* s_dead = reinterpret_cast<int*>(dbL + 4096);
+  int* s_word = s_dead + 1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -397,7 +482,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
-  unsigned* flags = a.flags + cl * NCL;
   constexpr int XSLAB = NCL * NCL * MT * 16 * US;  // floats per slab
   float* Xc = a.X + (size_t)cl * 3 * XSLAB;
   if (tid == 0) *s_dead = 0;
@@ -450,24 +534,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     cur[n][5] = (ok && T > 1) ? ldg4<0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
     cur[n][6] = ok ? ldg4<0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
   }
-  __syncthreads();
+  bool same_l2 = false;
+  if (NCL > 1) {
+    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, NCL, j, a.timeout_ticks, a.err, s_word);   // has a barrier
+    if (hs < 0) return;
+    same_l2 = hs == 1;
+  } else {
+    __syncthreads();
+  }
 
+  STAMP_DECL;
   for (int t = T - 1; t >= 0; --t) {
-    // prefetch step t-1 (its c_t is this step's c_{t-1}, already held)
+    STAMP(0);
     f32x4 nx[NQ][6];
-    if (t > 0) {
-#pragma unroll
-      for (int n = 0; n < NQ; ++n) {
-        const int e = tid + 256 * n;
-        const int row = (e / QPR) & 15, mt = e / (16 * QPR);
-        const long rr = mt * 16 + row;
-        const bool ok = e < NE;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
-        nx[n][4] = (ok && t > 1) ? ldg4<0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
-        nx[n][5] = ok ? ldg4<0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
-      }
-    }
     // (A) gate gradients for this member's units
     f32x4 dgv[NQ][4];
 #pragma unroll
@@ -498,11 +577,27 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         }
       }
     }
+    // prefetch step t-1 (its c_t is this step's c_{t-1}, already held): a whole step in flight, issued
+    // after the gate math so that no wait of that segment can fall on these fresh loads
+    if (t > 0) {
+#pragma unroll
+      for (int n = 0; n < NQ; ++n) {
+        const int e = tid + 256 * n;
+        const int row = (e / QPR) & 15, mt = e / (16 * QPR);
+        const long rr = mt * 16 + row;
+        const bool ok = e < NE;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
+        nx[n][4] = (ok && t > 1) ? ldg4<0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
+        nx[n][5] = ok ? ldg4<0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
+      }
+    }
+    STAMP(1);
     const bool last = t == 0;           // dh_{-1} is never used
-    const bool dataflag = (a.mode & 2) != 0;
-    const int par = dataflag ? t % 3 : (t & 1);   // exchange slab of this step
+    const int par = t % 3;              // exchange slab of this step
     if (!last) {
       __syncthreads();
+      STAMP(2);
       if (NCL > 1 && *s_dead) break;   // a re-poll timed out (set before the barrier: uniform)
       // (B) partial dh_{t-1}^T = W_hh[rows of this member]^T . dgates_t^T
       if (mactive) {
@@ -517,7 +612,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgHi + go));
             const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgLo + go));
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) acc[nt] = tb_mfma_bf16x3(wbh[nt][s], wbl[nt][s], bh, bl, acc[nt]);
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbh[nt][s], bl, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbl[nt][s], bh, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbh[nt][s], bh, acc[nt], 0, 0, 0);
           }
           // lane: batch row `col`, output units n0 .. n0+3
 #pragma unroll
@@ -525,18 +624,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             const int n0 = (wave * NTW + nt) * 16 + q * 4;
             const int m = n0 / US;
             if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
-            else stg4<kSC1>(rX, (long)par * XSLAB + ((long)(m * NCL + j) * MT * 16 + mt * 16 + col) * US + (n0 % US), acc[nt]);
+            else stx4(same_l2, rX, (long)par * XSLAB + ((long)(m * NCL + j) * MT * 16 + mt * 16 + col) * US + (n0 % US), acc[nt]);
           }
         }
       }
-      if (NCL > 1 && !dataflag) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) tb_store_agent_u32(flags + j, (unsigned)(T - t));
-        asm volatile("" ::: "memory");
-      } else {
-        __syncthreads();   // own columns of dhL visible
-      }
+      STAMP(3);
+      __syncthreads();   // own columns of dhL visible
+      STAMP(4);
     }
     // dgates of this step over the gate stash, in place (after the publish: not on its critical path)
 #pragma unroll
@@ -548,9 +642,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         for (int g = 0; g < 4; ++g) stg4<0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
       }
     }
+    STAMP(5);
     if (last) break;
-    if (NCL > 1 && !dataflag && !wait_members(flags, NCL, j, (unsigned)(T - t), a.timeout_ticks, a.err, s_dead)) break;
-    if (NCL > 1 && dataflag) {
+    if (NCL > 1) {
       // Data-as-flag: the slabs are armed with the sentinel (all-ones) before the launch, a slot that
       // holds a value is ready, and the consumer re-arms what it has consumed.  One wave polls one
       // piece per producer (the last one it stores), then every thread pulls its pieces and re-polls
@@ -560,8 +654,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         const unsigned long long t0 = wall_clock64();
         unsigned it = 0;
         while (true) {
-          const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rX, voff, 0, kSC1);
-          if (v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel) break;
+          if (!armed(__builtin_amdgcn_raw_buffer_load_b128(rX, voff, 0, kSC1))) break;
           __builtin_amdgcn_s_sleep(1);
           if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
             atomicExch(a.err, 1);
@@ -570,7 +663,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
           }
         }
       }
+      STAMP(6);
       __syncthreads();
+      STAMP(7);
       if (*s_dead) break;
     }
     // (C) reduce-scatter: dh_{t-1} for this member's units = own partial + the other members' partials
@@ -586,13 +681,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
           f32x4 v[NCL];
 #pragma unroll
           for (int m = 0; m < NCL; ++m) v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
-          if (dataflag) {
+          {
             unsigned pend = 0;
 #pragma unroll
-            for (int m = 0; m < NCL; ++m) {
-              const u32x4 b = __builtin_bit_cast(u32x4, v[m]);
-              if (m != j && (b[0] == kSentinel || b[1] == kSentinel || b[2] == kSentinel || b[3] == kSentinel)) pend |= 1u << m;
-            }
+            for (int m = 0; m < NCL; ++m)
+              if (m != j && armed(__builtin_bit_cast(u32x4, v[m]))) pend |= 1u << m;
             unsigned it = 0;
             unsigned long long t0 = 0;
             while (pend) {   // rare: a piece behind the polled one
@@ -601,8 +694,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
               for (int m = 0; m < NCL; ++m)
                 if ((pend >> m) & 1u) {
                   v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
-                  const u32x4 b = __builtin_bit_cast(u32x4, v[m]);
-                  if (b[0] != kSentinel && b[1] != kSentinel && b[2] != kSentinel && b[3] != kSentinel) pend &= ~(1u << m);
+                  if (!armed(__builtin_bit_cast(u32x4, v[m]))) pend &= ~(1u << m);
                 }
               if (pend && (++it & 255u) == 0) {
                 const unsigned long long now = wall_clock64();
@@ -621,21 +713,22 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[r] += other ? v[m][r] : 0.f;
           }
-          if (dataflag) {
+          {
             // Re-arm what was consumed.  The slab of step t is written again at step t-3; its writer
             // gets there only after consuming this member's partial of step t-2, which is stored
             // after the barrier that follows the NEXT step's copy of this wait -- and that wait
             // covers these stores.  So the re-arm always lands before the next write.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const f32x4 armed = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+            const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
 #pragma unroll
             for (int m = 0; m < NCL; ++m)
-              if (m != j) stg4<kSC1>(rX, base + (long)m * MT * 16 * US, armed);
+              if (m != j) stx4(same_l2, rX, base + (long)m * MT * 16 * US, arm);
           }
         }
         dhrec[n] = s;
       }
     }
+    STAMP(8);
     if (NCL == 1) __syncthreads();   // dhL free for the next step (NCL > 1: the waits' barriers order it)
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
@@ -644,6 +737,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       cur[n][5] = nx[n][4]; cur[n][6] = nx[n][5];
     }
   }
+  STAMP_FLUSH(1, cl, j);
   // bias grads of this cluster: reduce the threads that share a unit quad, one partial row per cluster
   __syncthreads();
 #pragma unroll
@@ -761,54 +855,41 @@ int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
 
 constexpr unsigned long long kTimeoutTicks = 200000000ull;   // 2 s of the 100 MHz realtime counter
 
-// Exchange protocol, bit 0 forward / bit 1 backward: 1 = data-as-flag (sentinel-armed buffers, no
-// store drain and no counter round trip; the default), 0 = drained write-through stores + per-member
-// step counters (Guideline 16 R1).  TB_LSTM_MODE overrides it (A/B measurements).
-int exchange_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("TB_LSTM_MODE");
-    mode = e ? atoi(e) : 3;
-  }
-  return mode;
-}
-
 // the kernels address one cluster's rows through 32-bit buffer descriptors
 bool tile_fits_descriptor(const Plan& p, int T, int H) {
   return (long long)p.rows_per_cluster * T * 4 * H * 4 < 0x7FFFFFFFll;
 }
 
-// workspace carve: [flags | bias sum | dbpart | X | gemm split-k slabs]
+// workspace carve: [hello | exchange (fwd: h ring, bwd: dh slabs) | bias sum | dbpart | gemm split-k slabs]
+// hello + exchange are contiguous: one 0xFF fill arms both before a launch
 struct Carve {
-  unsigned* flags; size_t flags_bytes;
+  unsigned* hello; size_t hello_bytes;
+  float* X; size_t x_bytes;
   float* bsum;
   float* dbpart;
-  float* X; size_t x_bytes;
   float* gemm_ws; size_t gemm_ws_bytes;
 };
 
 size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   size_t off = 0;
-  const size_t flags_bytes = tb_align_up((size_t)ncl_total * p.NCL * sizeof(unsigned), 256);
+  const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
+  const size_t hello_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * p.NCL * sizeof(unsigned), 256) : 0;
+  // rings of 3 slots per cluster: forward rows x H floats (h_t all-gather), backward NCL x rows x H
+  // (one partial of dh per producer, reduce-scatter)
+  const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * p.rows_per_cluster * H * sizeof(float), 256) : 0;
   const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
-  const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
-  const size_t x_bytes = (bwd && p.NCL > 1)
-                             ? tb_align_up((size_t)ncl_launch * 3 * p.NCL * p.rows_per_cluster * H * sizeof(float), 256)
-                             : 0;
   const int widest = in_dim > H ? in_dim : H;
   const size_t gemm_bytes = bwd ? tb_align_up((size_t)64 * 4 * H * widest * sizeof(float), 256) : 0;
-  if (c) {
-    c->flags = reinterpret_cast<unsigned*>(base + off); c->flags_bytes = flags_bytes;
-  }
-  off += flags_bytes;
+  if (c) { c->hello = reinterpret_cast<unsigned*>(base + off); c->hello_bytes = hello_bytes; }
+  off += hello_bytes;
+  if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
+  off += x_bytes;
   if (c) c->bsum = reinterpret_cast<float*>(base + off);
   off += bsum_bytes;
   if (c) c->dbpart = reinterpret_cast<float*>(base + off);
   off += dbpart_bytes;
-  if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
-  off += x_bytes;
   if (c) {
     c->gemm_ws = reinterpret_cast<float*>(base + off);
     c->gemm_ws_bytes = total > off ? total - off : 0;
@@ -820,6 +901,12 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
 }  // namespace
 
 extern "C" {
+
+#ifdef TB_STAMPS
+int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
+  return tb_check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(tb_stamps), sizeof(unsigned long long) * 2 * 4 * 12), "stamps");
+}
+#endif
 
 size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
   (void)T;
@@ -847,9 +934,6 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: T*H too large (%d x %d)", T, H);
-  const int mode = exchange_mode();
-  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
-  if (p.NCL > 1 && (mode & 1)) TB_HIP(hipMemsetAsync(y, 0xFF, (size_t)B * T * H * sizeof(float), s));
   // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash
   const float* bias = nullptr;
   if (b_ih && b_hh) {
@@ -867,13 +951,14 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     FwdArgs a;
     a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
-    a.flags = c.flags + (size_t)c0 * p.NCL;
+    a.ring = c.X;
+    a.hello = c.hello;
+    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.hello, 0xFF, c.hello_bytes + c.x_bytes, s));   // arm handshake + ring
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.nclusters = ncl;
     a.train = train;
-    a.mode = mode;
     a.timeout_ticks = kTimeoutTicks;
     rc = launch_fwd(p, a, ncl * p.NCL, s);
     if (rc) return rc;
@@ -897,7 +982,6 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: T*H too large (%d x %d)", T, H);
-  TB_HIP(hipMemsetAsync(c.flags, 0, c.flags_bytes, s));
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   int rc;
   // algorithmic bytes of one layer backward: read 5h stash + dy, read x, write dx
@@ -908,13 +992,12 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     a.G = gates; a.cst = cstash; a.dy = dy; a.Whh = w_hh;
     a.X = c.X;
     a.dbpart = c.dbpart;
-    a.flags = c.flags + (size_t)c0 * p.NCL;
+    a.hello = c.hello;
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.cl_begin = c0;
-    a.mode = exchange_mode();
-    if (p.NCL > 1 && (a.mode & 2)) TB_HIP(hipMemsetAsync(c.X, 0xFF, c.x_bytes, s));   // arm the slabs
+    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.hello, 0xFF, c.hello_bytes + c.x_bytes, s));   // arm handshake + slabs
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
     rc = launch_bwd(p, a, ncl * p.NCL, s);
