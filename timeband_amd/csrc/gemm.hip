@@ -42,6 +42,7 @@ struct GemmArgs {
   float* slab;
   int b_shift, b_period;
   int vecA, vecB;
+  int bytesA, bytesB;    // extents of the operands for the bounds-checked buffer loads
 };
 
 template <int LAY, int ROWS>
@@ -59,39 +60,31 @@ struct Tile {
     else { k = e / (ROWS / 4); r = (e % (ROWS / 4)) * 4; }
   }
 
-  static __device__ __forceinline__ void load(const float* __restrict__ src, long ld, int r0, int rlim, int k0,
-                                              int klim, int vec, int shift, int period, f32x4 (&v)[NCH]) {
+  // Branch-free tile load through a bounds-checked buffer descriptor: an element outside the matrix
+  // gets an offset past the descriptor's end and reads as 0.  (With per-lane branches around the loads
+  // hipcc waits for each load before it issues the next one: no prefetch at all.)
+  template <bool VEC>
+  static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, long ld, int r0, int rlim, int k0, int klim,
+                                              int shift, int period, f32x4 (&v)[NCH]) {
+    constexpr int kOob = 0x7FFFFFF0;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       int r, k;
       where(c, r, k);
       r += r0; k += k0;
-      v[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (NCHUNK < 256 && threadIdx.x >= NCHUNK) continue;
-      if (LAY == 0) {
-        if (r < rlim && k < klim) {
-          const float* p = src + (long)r * ld + k;
-          if (vec && k + 3 < klim) v[c] = *reinterpret_cast<const f32x4*>(p);
-          else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (k + i < klim) v[c][i] = p[i];
-          }
-        }
+      bool ok = r < rlim && k < klim && !(NCHUNK < 256 && (int)threadIdx.x >= NCHUNK);
+      if (LAY == 1 && shift) {   // B row k is source row k - shift, zero for the first `shift` rows of each period
+        ok = ok && (k % period) >= shift;
+        k -= shift;
+      }
+      const long e0 = LAY == 0 ? (long)r * ld + k : (long)k * ld + r;
+      if (VEC) {
+        v[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (int)(e0 * 4) : kOob, 0, 0));
       } else {
-        bool ok = k < klim && r < rlim;
-        if (shift) {   // B row k is source row k - shift, zero for the first `shift` rows of each period
-          ok = ok && (k % period) >= shift;
-          k -= shift;
-        }
-        if (ok) {
-          const float* p = src + (long)k * ld + r;
-          if (vec && r + 3 < rlim) v[c] = *reinterpret_cast<const f32x4*>(p);
-          else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (r + i < rlim) v[c][i] = p[i];
-          }
+        for (int i = 0; i < 4; ++i) {
+          const bool oki = ok && (LAY == 0 ? k + i < klim : r + i < rlim);
+          v[c][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oki ? (int)((e0 + i) * 4) : kOob, 0, 0));
         }
       }
     }
@@ -126,7 +119,10 @@ struct Tile {
   }
 };
 
-template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN>
+// FAST: both operands and the output are 16-byte addressable (pointers and leading dimensions multiples
+// of 4 floats, N a multiple of 4): one b128 load per chunk, one b128 store per epilogue piece, no
+// per-lane branches anywhere in the loop.  Otherwise dword loads / scalar tail stores.
+template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   using TA = Tile<LAY_A, BM>;
   using TB = Tile<LAY_B, BN>;
@@ -134,80 +130,141 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "bad wave layout");
   __shared__ __attribute__((aligned(16))) unsigned short Ah[TA::ELEMS], Al[TA::ELEMS];
   __shared__ __attribute__((aligned(16))) unsigned short Bh[TB::ELEMS], Bl[TB::ELEMS];
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
-  const int kbeg = z * a.kchunk;
-  const int kend = min(a.K, kbeg + a.kchunk);
+  constexpr int CW = TN * 16, PLD = CW + 4;             // epilogue patch: 16 rows x CW columns per wave
+  static_assert(64 % (CW / 4) == 0, "a lane must keep its epilogue columns over the patch rows");
+  __shared__ __attribute__((aligned(16))) float patch[4][16 * PLD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, q = lane >> 4;
   const int wm = wave / WGN, wn = wave % WGN;
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+  // Persistent over work items (output tile x k-split), n fastest: concurrent blocks then write whole
+  // rows of C between them (a row of C is a DRAM/TLB page at N = 1024; m-fastest order touched 128 pages
+  // per tile with 512 B each) and share the A tile in L2; B is the small operand and stays L2-resident.  The first k-tile of the NEXT item is loaded under the last MFMAs and the epilogue of
+  // the current one: small-K products (one or two k-tiles per item) pipeline across items.
+  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.N + BN - 1) / BN;
+  const int total = mtiles * ntiles * a.splits;
+  int w = blockIdx.x;
+  if (w >= total) return;
+  auto decode = [&](int item, int& m0, int& n0, int& z, int& kbeg, int& kend) {
+    z = item / (mtiles * ntiles);
+    const int r = item % (mtiles * ntiles);
+    // n fastest, rotated by the m tile: blocks b, b+8, ... share an XCD, and with a power-of-two number
+    // of n tiles they would all write the same columns of C -- the same few L2 / HBM channels
+    m0 = (r / ntiles) * BM;
+    n0 = ((r + r / ntiles) % ntiles) * BN;
+    kbeg = z * a.kchunk;
+    kend = min(a.K, kbeg + a.kchunk);
+  };
+  int m0, n0, z, kbeg, kend;
+  decode(w, m0, n0, z, kbeg, kend);
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.bytesB, 0x00020000);
   f32x4 ra[TA::NCH], rb[TB::NCH];
-  if (kbeg < kend) {
-    TA::load(a.A, a.lda, m0, a.M, kbeg, kend, a.vecA, 0, 1, ra);
-    TB::load(a.B, a.ldb, n0, a.N, kbeg, kend, a.vecB, a.b_shift, a.b_period, rb);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    TA::store(Ah, Al, ra);
-    TB::store(Bh, Bl, rb);
-    __syncthreads();
-    if (k0 + BK < kend) {   // next tile's global loads fly under this tile's MFMAs
-      TA::load(a.A, a.lda, m0, a.M, k0 + BK, kend, a.vecA, 0, 1, ra);
-      TB::load(a.B, a.ldb, n0, a.N, k0 + BK, kend, a.vecB, a.b_shift, a.b_period, rb);
+  TA::template load<FAST>(rA, a.lda, m0, a.M, kbeg, kend, 0, 1, ra);
+  TB::template load<FAST>(rB, a.ldb, n0, a.N, kbeg, kend, a.b_shift, a.b_period, rb);
+  while (true) {
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias of this lane's 4 epilogue columns (bounds-checked dword loads: 0 past N or without a bias),
+    // fetched before the k loop: a load inside the epilogue would drain every store issued before it
+    f32x4 bv;
+    {
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (a.bias && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const int nb = n0 + wn * CW + (lane % (CW / 4)) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, (nb + r) * 4, 0, 0));
+      // wait HERE (the operand tile loaded before it is needed now anyway): left to the compiler, the wait
+      // lands at the first use in the epilogue as vmcnt(0) and drains the stores issued before it
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    const int wnext = w + gridDim.x;
+    int m0n = 0, n0n = 0, zn = 0, kbegn = 0, kendn = 0;
+    if (wnext < total) decode(wnext, m0n, n0n, zn, kbegn, kendn);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      TA::store(Ah, Al, ra);
+      TB::store(Bh, Bl, rb);
+      __syncthreads();
+      if (k0 + BK < kend) {   // next k-tile's global loads fly under this tile's MFMAs
+        TA::template load<FAST>(rA, a.lda, m0, a.M, k0 + BK, kend, 0, 1, ra);
+        TB::template load<FAST>(rB, a.ldb, n0, a.N, k0 + BK, kend, a.b_shift, a.b_period, rb);
+      } else if (wnext < total) {
+        TA::template load<FAST>(rA, a.lda, m0n, a.M, kbegn, kendn, 0, 1, ra);
+        TB::template load<FAST>(rB, a.ldb, n0n, a.N, kbegn, kendn, a.b_shift, a.b_period, rb);
+      }
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = TA::frag(Ah, (wm * TM + i) * 16, col, q);
+        al[i] = TA::frag(Al, (wm * TM + i) * 16, col, q);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
+        bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
+      }
+      // three passes over the independent accumulators: no MFMA waits on the one before it.  The products
+      // are computed transposed (C^T = B^T.A^T: the B fragment is the MFMA's row operand), so a lane's four
+      // accumulator registers are four consecutive n of one output row: 16-byte epilogue stores.
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+      __syncthreads();   // all fragment reads done before the next tile overwrites the images
+    }
+
+    // Epilogue.  A lane holds 4 consecutive n of row m = col, so a direct store would send the 64 lanes of
+    // one instruction to 16 different rows (64 separate 16-byte writes).  Each wave turns its 16 x CW
+    // patches through a private LDS buffer instead, so that 16 consecutive lanes write one contiguous
+    // 256-byte piece of a row (LDS operations of one wave execute in order: no barrier needed).
+    float* out = a.splits > 1 ? a.slab + (size_t)z * a.M * a.N : a.C;
+    const long ldo = a.splits > 1 ? a.N : a.ldc;
+    float* pw = patch[wave];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      ah[i] = TA::frag(Ah, (wm * TM + i) * 16, col, q);
-      al[i] = TA::frag(Al, (wm * TM + i) * 16, col, q);
-    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
-      bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
-    }
-    // three passes over the independent accumulators: no MFMA waits on the one before it
+      for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(pw + col * PLD + j * 16 + q * 4) = acc[i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-    __syncthreads();   // all fragment reads done before the next tile overwrites the images
-  }
-
-  float* out = a.splits > 1 ? a.slab + (size_t)z * a.M * a.N : a.C;
-  const long ldo = a.splits > 1 ? a.N : a.ldc;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + (wn * TN + j) * 16 + col;
-      if (n >= a.N) continue;
-      const float bv = (a.splits == 1 && a.bias) ? a.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * TM + i) * 16 + q * 4 + r;
-        if (m >= a.M) continue;
-        float v = acc[i][j][r] + bv;
+      for (int k = 0; k < TN; ++k) {
+        const int idx = k * 64 + lane, row = idx / (CW / 4), c4 = idx % (CW / 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(pw + row * PLD + c4 * 4);
+        const int m = m0 + (wm * TM + i) * 16 + row;
+        const int n = n0 + wn * CW + c4 * 4;
+        if (m >= a.M || n >= a.N) continue;
+#ifdef TB_GEMM_NOSTORE
+        if (a.act != 77) continue;   // timing experiment: no global stores
+#endif
         if (a.splits == 1) {
-          if (a.act == 1) v = tanhf(v);
-          else if (a.act == 2) v = tb_sigmoid(v);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += bv[r];
+            if (a.act == 1) v[r] = tanhf(v[r]);
+            else if (a.act == 2) v[r] = tb_sigmoid(v[r]);
+          }
         }
-        out[(long)m * ldo + n] = v;
+        float* po = out + (long)m * ldo + n;
+        if (FAST) *reinterpret_cast<f32x4*>(po) = v;
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) po[r] = v[r];
+        }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (wnext >= total) break;
+    w = wnext; m0 = m0n; n0 = n0n; z = zn; kbeg = kbegn; kend = kendn;
+  }
 }
 
 // C[m][n] = act(sum_z slab[z][m][n] + bias[n]); fixed summation order.
@@ -225,12 +282,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits,
   }
 }
 
+template <int BM, int BN, int WGM, int WGN, bool FAST>
+void launch_lay(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
+  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 0, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
+  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 1, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
+  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 0, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
+}
+
 template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
-  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 0, BM, BN, WGM, WGN>), grid, dim3(256), 0, stream, a);
+  const bool out_vec = a.splits > 1 ? ((reinterpret_cast<uintptr_t>(a.slab) & 15) == 0 && (((size_t)a.M * a.N) & 3) == 0)
+                                    : ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0 && (a.ldc & 3) == 0);
+  if (a.vecA && a.vecB && out_vec && (a.N & 3) == 0) launch_lay<BM, BN, WGM, WGN, true>(a, transA, transB, grid, stream);
+  else launch_lay<BM, BN, WGM, WGN, false>(a, transA, transB, grid, stream);
 }
 
 }  // namespace
@@ -251,6 +316,13 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   a.b_period = b_period > 0 ? b_period : 1;
   a.vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (lda & 3) == 0) ? 1 : 0;
   a.vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0 && (ldb & 3) == 0) ? 1 : 0;
+  // the kernel addresses the operands through 32-bit buffer offsets
+  const long long exA = (transA ? (long long)(K - 1) * lda + M : (long long)(M - 1) * lda + K) * 4;
+  const long long exB = (transB ? (long long)(K - 1) * ldb + N : (long long)(N - 1) * ldb + K) * 4;
+  if (exA >= 0x7FFFFFF0ll || exB >= 0x7FFFFFF0ll)
+    return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: operand larger than 2 GiB (%lld / %lld bytes)", exA, exB);
+  a.bytesA = (int)exA;
+  a.bytesB = (int)exB;
   // tile shape by output width
   const int cfg = N <= 32 ? 0 : (N <= 64 ? 1 : 2);
   const int BM = cfg == 2 ? 128 : 256, BN = cfg == 0 ? 32 : (cfg == 1 ? 64 : 128);
@@ -272,7 +344,10 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   a.kchunk = kchunk;
   a.splits = splits;
   a.slab = ws;
-  dim3 grid(mt, nt, splits);
+  // persistent grid: as many blocks as stay resident (2 per CU by registers, 3 for the narrow tiles)
+  long items = tiles * splits;
+  const long resident = (long)cus * (cfg == 0 ? 3 : 2);
+  dim3 grid((unsigned)(items < resident ? items : resident));
   tb_prof_begin(TB_K_GEMM, stream);
   if (cfg == 0) launch_cfg<256, 32, 4, 1>(a, transA, transB, grid, stream);
   else if (cfg == 1) launch_cfg<256, 64, 4, 1>(a, transA, transB, grid, stream);
