@@ -123,15 +123,15 @@ int tb_linear_act_fwd(const float* x, const float* W, const float* b, float* y, 
   return tb_gemm_launch(x, K, 0, W, K, 0, y, N, b, M, N, K, act, 0, 1, nullptr, 0, static_cast<hipStream_t>(stream));
 }
 
+size_t tb_colsum_workspace_bytes(int cols);
 size_t tb_linear_workspace_bytes(int M, int K, int N) {
-  (void)M;
-  return (size_t)64 * N * K * sizeof(float) + (size_t)64 * N * sizeof(double) + 512;
+  (void)M; (void)K;
+  return tb_gemm_ws_bytes() + tb_align_up(tb_colsum_workspace_bytes(N), 256) + 512;
 }
 
 // dz = dy * act'(y) must already have been applied by the caller when act != 0 (tb_act_bwd).
 // dx[M,K] = dz.W ; dW[N,K] = dz^T.x ; db[N] = colsum(dz).  Any of dx/dW/db may be null.
 int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream);
-size_t tb_colsum_workspace_bytes(int cols);
 
 int tb_linear_bwd(const float* dz, const float* x, const float* W, float* dx, float* dW, float* db, int M, int K,
                   int N, void* ws, size_t ws_bytes, void* stream) {

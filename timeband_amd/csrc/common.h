@@ -20,6 +20,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 int tb_set_error(int code, const char* fmt, ...);
 int tb_check_hip(hipError_t e, const char* what);
 int tb_num_cus();
+size_t tb_gemm_ws_bytes();   // gemm.hip: upper bound of the split-K slabs
 
 #define TB_HIP(call)                                   \
   do {                                                 \

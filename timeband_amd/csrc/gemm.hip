@@ -300,6 +300,10 @@ void launch_cfg(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_
 
 }  // namespace
 
+// Split-K slab bound: splits are chosen so that tiles x splits fills the chip twice over, and only when
+// there are fewer tiles than CUs, so the slabs never exceed (3 x CUs) tiles of 128 x 128 floats.
+size_t tb_gemm_ws_bytes() { return (size_t)3 * tb_num_cus() * 128 * 128 * sizeof(float); }
+
 // Host-side launcher shared by the C-ABI entry points (capi.hip, lstm.hip).
 // transA: 0 -> A is [M][K]; 1 -> A is [K][M].   transB: 0 -> B is [N][K]; 1 -> B is [K][N].
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
@@ -334,7 +338,7 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
     splits = (int)((2L * cus + tiles - 1) / tiles);
     const int maxs = K / (8 * BK);
     if (splits > maxs) splits = maxs;
-    if (splits > 64) splits = 64;
+    if (splits > 512) splits = 512;
     while (splits > 1 && (size_t)splits * M * N * sizeof(float) > ws_bytes) --splits;
     if (splits < 1) splits = 1;
   }

@@ -880,8 +880,8 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * p.rows_per_cluster * H * sizeof(float), 256) : 0;
   const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
-  const int widest = in_dim > H ? in_dim : H;
-  const size_t gemm_bytes = bwd ? tb_align_up((size_t)64 * 4 * H * widest * sizeof(float), 256) : 0;
+  (void)in_dim;
+  const size_t gemm_bytes = bwd ? tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
   if (c) { c->hello = reinterpret_cast<unsigned*>(base + off); c->hello_bytes = hello_bytes; }
   off += hello_bytes;
   if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
