@@ -79,7 +79,7 @@ struct FwdArgs {
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
-  float* ring;         // [nclusters][3][MT*16][H] exchange ring (NCL > 1), sentinel-armed before the launch
+  float* ring;         // [nclusters][3][MT*16][H] exchange ring (NCL > 1) of {bf16 hi | bf16 lo} words, sentinel-armed before the launch
   unsigned* hello;     // [nclusters][NCL] start-up handshake words, sentinel-armed before the launch
   int* err;            // [4] sticky error words
   int B, T;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     STAMP(2);
     if (fin) {
       // (C) gate math, state update, h into LDS, the ring and y -- 4 consecutive units of one batch row per lane
-      f32x4 st[MT][4], hn[MT];
+      f32x4 st[MT][4], hn[MT], hx[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 z[4];
@@ -330,6 +330,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         tb_split4(hn[mt], sh, sl);
         *reinterpret_cast<u32x2*>(hiL + (mt * 16 + col) * LDH + u0) = sh;
         *reinterpret_cast<u32x2*>(loL + (mt * 16 + col) * LDH + u0) = sl;
+        // the ring carries h already split, one {hi:16 | lo:16} word per element: the consumers only
+        // regroup the halves (2 v_perm per pair) instead of splitting again
+        hx[mt] = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
+                                                  __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
       }
       if (exchange) {
         // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         STAMP(6);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hn[mt]);
+        for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx[mt]);
       }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) stg4<0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn[mt]);
@@ -420,8 +424,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         const int m = pw + (n / LPP) * NPW;
         const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
         if (m < NCL && m != j) {
-          u32x2 sh, sl;
-          tb_split4(__builtin_bit_cast(f32x4, buf[n]), sh, sl);
+          const u32x2 sh = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x07060302u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x07060302u)};
+          const u32x2 sl = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x05040100u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x05040100u)};
           *reinterpret_cast<u32x2*>(hiL + row * LDH + m * US + c4 * 4) = sh;
           *reinterpret_cast<u32x2*>(loL + row * LDH + m * US + c4 * 4) = sl;
         }
