@@ -43,7 +43,7 @@ class Runtime:
         with torch.cuda.device(device):
             _lib.call("tb_init", device.index if device.index is not None else torch.cuda.current_device())
         self.err = torch.zeros(4, dtype=torch.int32, device=device)
-        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+        self._ws = {}       # one workspace per stream: launches on different streams may run concurrently
 
     @classmethod
     def get(cls, device):
@@ -56,9 +56,11 @@ class Runtime:
         return rt
 
     def workspace(self, nbytes):
-        if self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = self._ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return ws
 
     def check(self):
         """Host sync: raise if a persistent kernel reported an inter-workgroup wait timeout."""

@@ -15,6 +15,8 @@ Data parallel: one process per GPU, every rank holds the same parameters and ste
 contiguous shard of each global batch; gradients are summed with ONE all-reduce per network over
 the flat gradient buffer (RCCL over xGMI), the gradient-penalty norm with one 8-double all-reduce.
 """
+import os
+
 import torch
 
 from . import ops
@@ -34,6 +36,11 @@ class TIMEBANDTrainer:
         self.forecast_len = self.dataset.forecast_len
         self.post = BandAdjust(dataset, "trainer", self.band_width, self.missing_gamma, self.anomaly_gamma)
         self.optimD = self.optimG = None
+        # The two generator forwards of an iteration depend only on G's parameters, which do not change
+        # until the very end: they run on side streams, under the critic step and under the D-phase
+        # backward (latency-bound persistent kernels leave most of the chip idle).  TB_OVERLAP=0: one stream.
+        self.overlap = os.environ.get("TB_OVERLAP", "1") != "0"
+        self._side = None
 
     def set_config(self, config: dict = None) -> None:
         self.__dict__ = {**config, **self.__dict__}
@@ -119,6 +126,16 @@ class TIMEBANDTrainer:
         """trainer.py:142-194.  `critic_batches`: iterable of (x, y) critic draws (default: `critic`
         draws from dataset.get_random()).  Returns the G-phase fake_y."""
         netD, netG = self.models.netD, self.models.netG
+        overlap = self.overlap and training and true_x.is_cuda
+        if overlap:
+            main = torch.cuda.current_stream(true_x.device)
+            if self._side is None:
+                self._side = (torch.cuda.Stream(true_x.device), torch.cuda.Stream(true_x.device))
+            s1, s2 = self._side
+            s1.wait_stream(main)
+            with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step
+                fake_y = netG(true_x)
+            fake_y.record_stream(main)
         if training:
             self._critic_opt = FusedRMSprop(netD, self.lr * self.lr_gammaD)
             if critic_batches is None:
@@ -134,9 +151,17 @@ class TIMEBANDTrainer:
         self.optimG.zero_grad()
         # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
         with torch.set_grad_enabled(training):
-            fake_y = netG(true_x)
+            if overlap:
+                main.wait_stream(s1)
+            else:
+                fake_y = netG(true_x)
             Dy, DGx = netD.pair(true_y, fake_y)
             errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx)
+        if overlap:
+            s2.wait_stream(main)
+            with torch.cuda.stream(s2):          # G-phase generator forward, under the D-phase backward
+                fake_y2 = netG(true_x)
+            fake_y2.record_stream(main)
         if training:
             errD.backward()
             self.optimD.all_reduce_grads()
@@ -149,7 +174,11 @@ class TIMEBANDTrainer:
             p.requires_grad_(False)
         try:
             with torch.set_grad_enabled(training):
-                fake_y = netG(true_x)
+                if overlap:
+                    main.wait_stream(s2)
+                    fake_y = fake_y2
+                else:
+                    fake_y = netG(true_x)
                 DGx = netD(fake_y)
                 errG = self.losses.gen_loss(true_y, fake_y, DGx)
             if training:
