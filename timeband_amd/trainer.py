@@ -131,6 +131,9 @@ class TIMEBANDTrainer:
             main = torch.cuda.current_stream(true_x.device)
             if self._side is None:
                 self._side = (torch.cuda.Stream(true_x.device), torch.cuda.Stream(true_x.device))
+                # G's parameter gradients are produced on the side streams and accumulated into leaves
+                # created on the main one: intended here
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             s1, s2 = self._side
             s1.wait_stream(main)
             with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step

@@ -43,3 +43,19 @@ span = int(seg[-1]["End_Timestamp"]) - t0
 print(f"step span {span / 1e6:.3f} ms, kernel busy {busy / 1e6:.3f} ms, {len(seg)} dispatches")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{v[1] / 1e3:9.1f}us n={v[0]:3d} avg={v[1] / v[0] / 1e3:8.1f}us {k[0]} grid={k[1]},{k[2]},{k[3]}")
+# concurrency of the last step: union of busy intervals vs their sum, and per-queue busy time
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in seg)
+union, cur_s, cur_e = 0, None, None
+for s_, e_ in iv:
+    if cur_e is None or s_ > cur_e:
+        if cur_e is not None:
+            union += cur_e - cur_s
+        cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+union += (cur_e - cur_s) if cur_e is not None else 0
+print(f"union busy {union / 1e6:.3f} ms vs sum {busy / 1e6:.3f} ms (overlap {100 * (1 - union / busy):.1f} %), idle {(span - union) / 1e6:.3f} ms")
+perq = defaultdict(int)
+for r in seg:
+    perq[r.get("Queue_Id", "?")] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("busy per queue (ms):", {k: round(v / 1e6, 3) for k, v in perq.items()})
