@@ -156,6 +156,8 @@ class TIMEBANDTrainer:
         with torch.set_grad_enabled(training):
             if overlap:
                 main.wait_stream(s1)
+                # cut the graph at fake_y: D's backward runs on this stream, G's (below) on the side one
+                fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
             else:
                 fake_y = netG(true_x)
             Dy, DGx = netD.pair(true_y, fake_y)
@@ -167,6 +169,10 @@ class TIMEBANDTrainer:
             fake_y2.record_stream(main)
         if training:
             errD.backward()
+            if overlap:      # the generator's share of errD.backward(), under the G-phase discriminator pass
+                s1.wait_stream(main)
+                with torch.cuda.stream(s1):
+                    fake_g.backward(fake_y.grad)
             self.optimD.all_reduce_grads()
             self.optimD.step()
         # generator phase.  errG.backward() of the reference also accumulates into D's parameter
@@ -179,13 +185,19 @@ class TIMEBANDTrainer:
             with torch.set_grad_enabled(training):
                 if overlap:
                     main.wait_stream(s2)
-                    fake_y = fake_y2
+                    fake_g, fake_y = fake_y2, fake_y2.detach().requires_grad_()
                 else:
                     fake_y = netG(true_x)
                 DGx = netD(fake_y)
                 errG = self.losses.gen_loss(true_y, fake_y, DGx)
             if training:
                 errG.backward()
+                if overlap:  # G-phase generator backward after the D-phase one (both add into G's gradients)
+                    s2.wait_stream(main)
+                    s2.wait_stream(s1)
+                    with torch.cuda.stream(s2):
+                        fake_g.backward(fake_y.grad)
+                    main.wait_stream(s2)
         finally:
             for p in dparams:
                 p.requires_grad_(True)
