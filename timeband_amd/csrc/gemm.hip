@@ -267,13 +267,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   }
 }
 
-// C[m][n] = act(sum_z slab[z][m][n] + bias[n]); fixed summation order.
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int splits, int M, int N, float* C,
-                                     long ldc, const float* bias, int act) {
+// Split-K reduction in a fixed order (bitwise reproducible), two levels so that it parallelises over the
+// splits as well as over the elements: splitk_group sums groups of kGroup consecutive slabs into the
+// first slab of each group; splitk_final sums the group leaders, adds the bias, applies the activation.
+constexpr int kGroup = 16;
+
+__global__ void splitk_group_kernel(float* __restrict__ slab, int splits, long total4) {
+  const int g0 = blockIdx.y * kGroup;
+  const int g1 = min(splits, g0 + kGroup);
+  f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 a = s4[(size_t)g0 * total4 + i];
+    for (int z = g0 + 1; z < g1; ++z) a += s4[(size_t)z * total4 + i];
+    s4[(size_t)g0 * total4 + i] = a;
+  }
+}
+
+// C[m][n] = act(sum over z = 0, zstep, 2*zstep, ... < splits of slab[z][m][n] + bias[n])
+__global__ void splitk_final_kernel(const float* __restrict__ slab, int splits, int zstep, int M, int N, float* C,
+                                    long ldc, const float* bias, int act) {
   const long total = (long)M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += slab[(size_t)z * total + i];
+    for (int z = 0; z < splits; z += zstep) s += slab[(size_t)z * total + i];
     const int m = (int)(i / N), n = (int)(i % N);
     if (bias) s += bias[n];
     if (act == 1) s = tanhf(s);
@@ -359,11 +375,20 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   TB_LAUNCH_CHECK("gemm_bf16x3_kernel");
   if (splits > 1) {
     const long total = (long)M * N;
+    int zstep = 1;
+    if (splits > kGroup && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+      int bx = (int)((total / 4 + 255) / 256);
+      if (bx > 1024) bx = 1024;
+      hipLaunchKernelGGL(splitk_group_kernel, dim3(bx, (splits + kGroup - 1) / kGroup), dim3(256), 0, stream, ws, splits,
+                         total / 4);
+      TB_LAUNCH_CHECK("splitk_group_kernel");
+      zstep = kGroup;
+    }
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, M, N, C, ldc, bias,
+    hipLaunchKernelGGL(splitk_final_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, zstep, M, N, C, ldc, bias,
                        act);
-    TB_LAUNCH_CHECK("splitk_reduce_kernel");
+    TB_LAUNCH_CHECK("splitk_final_kernel");
   }
   tb_prof_end(TB_K_GEMM, stream);
   return TB_OK;
