@@ -67,6 +67,17 @@ int tb_act_bwd(const float* dy, const float* y, float* dz, long n, int act, void
 size_t tb_colsum_workspace_bytes(int cols);
 int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Single-output head out[m] = act(x[m,:].w + b): the discriminator's nn.Linear(hidden, 1) + Sigmoid,
+ * source/utils/lstm_layer.py:76,84-87 (forward) and its autograd (backward), as streaming kernels
+ * instead of a one-column GEMM.  K % 4 == 0, K <= 1024 (tb_head_supported), x / w / dx 16-byte aligned.
+ * Backward: dy = gradient wrt out, out = the forward result (read when act != 0); dx[M,K], dw[K], db[1]
+ * are each optional.  Workspace: tb_head_workspace_bytes(M, K). */
+int tb_head_supported(int K);
+size_t tb_head_workspace_bytes(long M, int K);
+int tb_head_fwd(const float* x, const float* w, const float* b, float* out, long M, int K, int act, void* stream);
+int tb_head_bwd(const float* dy, const float* out, const float* x, const float* w, float* dx, float* dw, float* db,
+                long M, int K, int act, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- losses (source/loss.py) ---------------------------------------------------------------------
  * tb_loss_sums: one pass over whichever inputs are non-NULL into a device double[8]:
  *   [0] sum (Dy-0.9)^2  [1] sum (DGx-0.1)^2  [2] sum Dy  [3] sum DGx  [4] sum SmoothL1(pred-true)

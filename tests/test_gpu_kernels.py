@@ -54,7 +54,8 @@ def test_library_loaded_is_hip():
 
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,K,N,act", [(64, 16, 64, 0), (100, 11, 7, 1), (333, 36, 256, 0), (130, 256, 1, 2),
-                                        (48 * 5, 48, 48, 0), (1000, 128, 32, 1), (17, 5, 3, 0)])
+                                        (48 * 5, 48, 48, 0), (1000, 128, 32, 1), (17, 5, 3, 0),
+                                        (5000, 512, 1, 2), (77, 64, 1, 0), (300, 1024, 1, 1), (9, 6, 1, 2)])
 def test_linear_fwd_bwd(dev, M, K, N, act):
     """GEMM operands are split bf16 hi+lo (2^-17 relative each, lo.lo dropped): a single product is
     good to ~1.5e-5, sums over k average below that.  north_star's bar is 1e-4 forward / 1e-3 gradients."""

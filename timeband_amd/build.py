@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtimeband_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "lstm.hip", "losses.hip", "postproc.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "lstm.hip", "losses.hip", "postproc.hip", "head.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -34,7 +34,7 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, jobs=5, stamps=False):
+def build(force=False, verbose=True, jobs=6, stamps=False):
     """stamps=True: diagnostic build with in-kernel cycle stamps (libtimeband_hip_stamps.so, tools only)."""
     if stamps:
         return _build(os.path.join(HERE, "build_stamps"), os.path.join(HERE, "libtimeband_hip_stamps.so"),

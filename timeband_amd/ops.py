@@ -190,8 +190,48 @@ class _LinearActFn(torch.autograd.Function):
         return dx, dW, db, None
 
 
+class _HeadFn(torch.autograd.Function):
+    """act(x @ w.T + b) for a single output column (the discriminator head): streaming kernels."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        _need_cuda(x, W, b)
+        x, W = _f32c(x), _f32c(W)
+        b = _f32c(b) if b is not None else None
+        M, K = x.shape
+        y = torch.empty(M, 1, dtype=torch.float32, device=x.device)
+        _lib.call("tb_head_fwd", _ptr(x), _ptr(W), _ptr(b), _ptr(y), M, K, act, _stream())
+        ctx.save_for_backward(x, W, y)
+        ctx.act = act
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        M, K = x.shape
+        dy = _f32c(dy)
+        dev = x.device
+        rt = Runtime.get(dev)
+        need = ctx.needs_input_grad
+        dx = torch.empty_like(x) if need[0] else None
+        dW = torch.empty_like(W) if need[1] else None
+        db = torch.empty(1, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
+        ws = rt.workspace(_lib.load().tb_head_workspace_bytes(M, K))
+        _lib.call("tb_head_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, ctx.act,
+                  _ptr(ws), ws.numel(), _stream())
+        return dx, dW, db, None
+
+
+def _aligned16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
 def linear_act(x2d, W, b, act=ACT_NONE):
     """act(x2d @ W.T + b) for a 2-D x."""
+    if W.shape[0] == 1 and _lib.load().tb_head_supported(W.shape[1]) and x2d.is_contiguous() and W.is_contiguous() \
+            and _aligned16(x2d, W):
+        return _HeadFn.apply(x2d, W, b, act)
     return _LinearActFn.apply(x2d, W, b, act)
 
 
