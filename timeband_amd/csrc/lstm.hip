@@ -173,21 +173,21 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NKS = KPER / 32;        // 32-deep MFMA k-steps per wave
   constexpr int LDH = HK + 8;           // LDS row stride of the h tile (bf16 elements; 16-byte pad)
   constexpr int NACT = NUG * KS;        // waves doing MFMA work
-  constexpr int RED = (KS - 1) * NUG * MT * 4 * 256;   // floats of k-split scratch
+  constexpr int RED = (KS - 1) * NUG * 4 * 256;        // floats of k-split scratch (one tile at a time)
   // exchange (NCL > 1): waves [0, NUG) finish the gates and publish, waves [NUG, 4) pull
   constexpr int NPW = NCL > 1 ? 4 - NUG : 1;            // puller waves
   constexpr int NPP = (NCL + NPW - 1) / NPW;            // producers per puller wave
-  constexpr int LPP = MT * 16 * (US / 4) / 64;          // 16-byte loads per lane per producer
+  constexpr int LPP = 16 * (US / 4) / 64;               // 16-byte loads per lane per producer (one 16-row tile)
   constexpr int NLD = NPP * LPP;                        // loads per lane per step
   constexpr int RS = MT * 16 * H;                       // floats per ring slot
   static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0, "bad config");
-  static_assert(NCL == 1 || (NUG < 4 && (MT * 16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
+  static_assert(NCL == 1 || (NUG < 4 && (16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // h_{t-1} tile as split bf16 (hi, lo): [MT*16 rows][LDH], one ds_read_b128 per MFMA B operand
   unsigned short* hiL = reinterpret_cast<unsigned short*>(smem);
   unsigned short* loL = hiL + MT * 16 * LDH;
-  float* red = smem + MT * 16 * LDH;                   // [MT][NUG][KS-1][4][64][4]
+  float* red = smem + MT * 16 * LDH;                   // [NUG][KS-1][4][64][4]
   int* s_dead = reinterpret_cast<int*>(red + RED);
   int* s_word = s_dead + 1;
 
@@ -251,35 +251,38 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
   { unsigned xx; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xx)); stamp_acc[11] = (unsigned long long)xx * T; }
 #endif
+  // Schedule.  The MT batch tiles of a cluster are independent recurrences; they are stepped in turn
+  // ("phases"), each phase = MFMA of one tile, then -- concurrently -- the finishing waves' gate math
+  // and publish for that tile and the puller waves' pull for the tile whose MFMA comes NEXT:
+  //   phase (t, x):  MFMA_x(t) | barrier | gates_x(t), publish h_x(t)  ||  pull for tile (x+1) % MT | barrier
+  // so with MT >= 2 a tile's hand-off (publish -> visible -> pulled) hides under another tile's MFMA and
+  // gate math, and a step of the cluster costs MT x (MFMA + max(gates, pull)) instead of
+  // MT x (MFMA + gates) + hand-off + pull.  The pull of phase x < MT-1 fetches h_{x+1}(t-1), the pull
+  // of phase MT-1 fetches h_0(t); MT == 1 is the plain schedule.
   for (int t = 0; t < T; ++t) {
-    STAMP(0);
-    const bool exchange = NCL > 1 && t + 1 < T;
-    // (A) every consumer has read h_{t-2} (it published h_{t-1} after that, and the pull of h_{t-1} is
-    // complete): re-arm this member's slice of that slot, which is written next at step t+1
-    if (NCL > 1 && fin && t >= 2) {
-      const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
-    }
-    // next step's pre-activations: independent of the recurrence.  Issued HERE, where no hand-off load of
-    // this CU is pending for the next ~3000 cycles: loads return in order per CU, so an HBM miss issued
-    // just before the polls would hold every poll and pull behind it (measured: +2000 cycles per step)
-    f32x4 nxt[MT][4];
-    if (t + 1 < T && fin) {
+    for (int x = 0; x < MT; ++x) {
+      const int mt = x;
+      STAMP(0);
+      // (A) every consumer has read h_mt(t-2) (it published h_mt(t-1) after that, and our pull of
+      // h_mt(t-1) is complete): re-arm this member's slice of that slot, which is written next at step t+1
+      if (NCL > 1 && fin && t >= 2) {
+        const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+        stx4(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
+      }
+      // next step's pre-activations of this tile: independent of the recurrence.  Issued HERE, where no
+      // hand-off load of these waves follows: loads return in order, so an HBM miss issued just before a
+      // poll holds the poll and the pull behind it (measured: +2000 cycles per step)
+      f32x4 nxt[4];
+      if (t + 1 < T && fin) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < 4; ++g) nxt[g] = ldg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
+      }
+      // (B) (W_hh . h_{t-1}^T) on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
+      f32x4 acc[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nxt[mt][g] = ldg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
-    }
-    // (B) (W_hh . h_{t-1}^T) on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) acc[mt][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (t > 0 && active) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+      for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t > 0 && active) {
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
           const int ho = (mt * 16 + col) * LDH + kp * KPER + s * 32 + q * 8;
@@ -287,153 +290,145 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(loL + ho));
           // three passes over the four independent accumulators: no MFMA waits on the one before it
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bl, acc[mt][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bl, acc[g], 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][s], bh, acc[mt][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][s], bh, acc[g], 0, 0, 0);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc[mt][g], 0, 0, 0);
+          for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc[g], 0, 0, 0);
         }
         if (KS > 1 && kp > 0) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + kp - 1) * 4 + g) * 64 + lane) * 4) = acc[mt][g];
+            *reinterpret_cast<f32x4*>(red + (((ug * (KS - 1) + kp - 1) * 4 + g) * 64 + lane) * 4) = acc[g];
         }
       }
-    }
-    STAMP(1);
-    __syncthreads();   // all reads of the h tile done; k-split partials visible
-    STAMP(2);
-    if (fin) {
-      // (C) gate math, state update, h into LDS, the ring and y -- 4 consecutive units of one batch row per lane
-      f32x4 st[MT][4], hn[MT], hx[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 z[4];
+      STAMP(1);
+      __syncthreads();   // all reads of this tile's h done; k-split partials visible
+      STAMP(2);
+      // which tile / step the puller waves fetch in this phase (for the MFMA of the next phase)
+      const int pt = (x + 1 < MT) ? x + 1 : 0;
+      const int ps = (x + 1 < MT) ? t - 1 : t;
+      const bool pull = NCL > 1 && ps >= 0 && ps + 1 < T;
+      if (fin) {
+        // (C) gate math, state update, h into LDS, the ring and y -- 4 consecutive units of one batch row per lane
+        f32x4 st[4], hn, hx, z[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          z[g] = acc[mt][g] + pre[mt][g];
+          z[g] = acc[g] + pre[mt][g];
           if (KS > 1 && t > 0) {
 #pragma unroll
             for (int p2 = 0; p2 < KS - 1; ++p2)
-              z[g] += *reinterpret_cast<const f32x4*>(red + ((((mt * NUG + ug) * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
+              z[g] += *reinterpret_cast<const f32x4*>(red + (((ug * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
           }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float ig = fsig(z[0][r]), fg = fsig(z[1][r]), gg = ftanh(z[2][r]), og = fsig(z[3][r]);
-          const float cn = fg * c[mt][r] + ig * gg;
+          // explicit fma: left to -ffp-contract the compiler picks either product, differently per instantiation
+          const float cn = __builtin_fmaf(fg, c[mt][r], ig * gg);
           c[mt][r] = cn;
-          hn[mt][r] = og * ftanh(cn);
-          st[mt][0][r] = ig; st[mt][1][r] = fg; st[mt][2][r] = gg; st[mt][3][r] = og;
+          hn[r] = og * ftanh(cn);
+          st[0][r] = ig; st[1][r] = fg; st[2][r] = gg; st[3][r] = og;
         }
         u32x2 sh, sl;
-        tb_split4(hn[mt], sh, sl);
+        tb_split4(hn, sh, sl);
         *reinterpret_cast<u32x2*>(hiL + (mt * 16 + col) * LDH + u0) = sh;
         *reinterpret_cast<u32x2*>(loL + (mt * 16 + col) * LDH + u0) = sl;
         // the ring carries h already split, one {hi:16 | lo:16} word per element: the consumers only
         // regroup the halves (2 v_perm per pair) instead of splitting again
-        hx[mt] = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
-                                                  __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
-      }
-      if (exchange) {
-        // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
-        // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
-        // of a wave complete in order: all but the 4*MT prefetch loads issued after the re-arm.
-        STAMP(5);
-        if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (MT == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        STAMP(6);
+        hx = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
+                                              __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
+        if (NCL > 1 && t + 1 < T) {
+          // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
+          // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
+          // of a wave complete in order: all but the 4 prefetch loads issued after the re-arm.
+          STAMP(5);
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          STAMP(6);
+          stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
+        }
+        stg4<0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn);
+        STAMP(3);
+        if (a.train) {   // BPTT stash: activated gates over P in place, cell state
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx[mt]);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) stg4<0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn[mt]);
-      STAMP(3);
-      if (a.train) {   // BPTT stash: activated gates over P in place, cell state
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[mt][g]);
+          for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[g]);
           stg4<0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, c[mt]);
         }
-      }
-      STAMP(4);
+        STAMP(4);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[g];
+      } else if (pull) {
+        // (D) puller waves: the other members' slices of h_pt(ps) from the ring into the LDS tile.  The
+        // ring is sentinel-armed and every slot word is written once per turn, so the data is its own ready
+        // flag: poll the last piece each storing wave of each of my producers writes, then pull, then
+        // re-pull whatever is still armed.  These waves issue no other memory traffic, so nothing queues
+        // before the hand-off in their memory counters.
+        const int pw = wave - NUG;
+        const long sbase = (long)(ps % 3) * RS + (long)pt * 16 * H;
+        if (lane < NPP * NUG) {
+          const int m = pw + (lane / NUG) * NPW;
+          if (m < NCL && m != j) {
+            const int voff = (int)((sbase + (long)15 * H + m * US + (lane % NUG) * 16 + 12) * 4);
+            const unsigned long long t0 = wall_clock64();
+            unsigned it = 0;
+            while (armed(__builtin_amdgcn_raw_buffer_load_b128(rR, voff, 0, kSC1))) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
+                atomicExch(a.err, 1);
+                *s_dead = 1;
+                break;
+              }
+            }
+          }
+        }
+        STAMP(5);
+        u32x4 buf[NLD];
+        unsigned pend = 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[mt][g];
-    } else if (exchange) {
-      // (D) puller waves: the other members' slices of h_t from the ring into the LDS tile.  The ring is
-      // sentinel-armed and every slot word is written once per turn, so the data is its own ready flag:
-      // poll the last piece each storing wave of each of my producers writes, then pull, then re-pull
-      // whatever is still armed.  These waves issue no other memory traffic, so nothing queues before
-      // the hand-off in their memory counters.
-      const int pw = wave - NUG;
-      const long sbase = (long)(t % 3) * RS;
-      if (lane < NPP * NUG) {
-        const int m = pw + (lane / NUG) * NPW;
-        if (m < NCL && m != j) {
-          const int voff = (int)((sbase + (long)(MT * 16 - 1) * H + m * US + (lane % NUG) * 16 + 12) * 4);
-          const unsigned long long t0 = wall_clock64();
-          unsigned it = 0;
-          while (armed(__builtin_amdgcn_raw_buffer_load_b128(rR, voff, 0, kSC1))) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
+        for (int n = 0; n < NLD; ++n) {
+          const int m = pw + (n / LPP) * NPW;
+          if (m < NCL && m != j) pend |= 1u << n;
+        }
+        unsigned it = 0;
+        unsigned long long t0 = 0;
+        while (pend) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int n = 0; n < NLD; ++n) {
+            const int m = pw + (n / LPP) * NPW;
+            const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
+            if ((pend >> n) & 1u) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
+          }
+#pragma unroll
+          for (int n = 0; n < NLD; ++n)
+            if (((pend >> n) & 1u) && !armed(buf[n])) pend &= ~(1u << n);
+          if (pend && (++it & 255u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > a.timeout_ticks) {
               atomicExch(a.err, 1);
               *s_dead = 1;
               break;
             }
           }
         }
-      }
-      STAMP(5);
-      u32x4 buf[NLD];
-      unsigned pend = 0;
-#pragma unroll
-      for (int n = 0; n < NLD; ++n) {
-        const int m = pw + (n / LPP) * NPW;
-        if (m < NCL && m != j) pend |= 1u << n;
-      }
-      unsigned it = 0;
-      unsigned long long t0 = 0;
-      while (pend) {
-        asm volatile("" ::: "memory");
+        STAMP(7);
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
           const int m = pw + (n / LPP) * NPW;
-          const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
-          if ((pend >> n) & 1u) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
-        }
-#pragma unroll
-        for (int n = 0; n < NLD; ++n)
-          if (((pend >> n) & 1u) && !armed(buf[n])) pend &= ~(1u << n);
-        if (pend && (++it & 255u) == 0) {
-          const unsigned long long now = wall_clock64();
-          if (t0 == 0) t0 = now;
-          else if (now - t0 > a.timeout_ticks) {
-            atomicExch(a.err, 1);
-            *s_dead = 1;
-            break;
+          const int pc = (n % LPP) * 64 + lane, row = pt * 16 + pc / (US / 4), c4 = pc % (US / 4);
+          if (m < NCL && m != j) {
+            const u32x2 sh = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x07060302u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x07060302u)};
+            const u32x2 sl = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x05040100u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x05040100u)};
+            *reinterpret_cast<u32x2*>(hiL + row * LDH + m * US + c4 * 4) = sh;
+            *reinterpret_cast<u32x2*>(loL + row * LDH + m * US + c4 * 4) = sl;
           }
         }
       }
-      STAMP(7);
-#pragma unroll
-      for (int n = 0; n < NLD; ++n) {
-        const int m = pw + (n / LPP) * NPW;
-        const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
-        if (m < NCL && m != j) {
-          const u32x2 sh = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x07060302u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x07060302u)};
-          const u32x2 sl = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x05040100u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x05040100u)};
-          *reinterpret_cast<u32x2*>(hiL + row * LDH + m * US + c4 * 4) = sh;
-          *reinterpret_cast<u32x2*>(loL + row * LDH + m * US + c4 * 4) = sl;
-        }
-      }
+      STAMP(8);
+      __syncthreads();   // the pulled tile is complete for its MFMA in the next phase
+      STAMP(9);
     }
-    STAMP(8);
-    __syncthreads();   // h tile complete for step t+1
-    STAMP(9);
     if (NCL > 1 && *s_dead) break;
   }
   STAMP_FLUSH(0, cl, j);
@@ -779,7 +774,11 @@ struct Plan {
   size_t lds_fwd, lds_bwd;
 };
 
-bool make_plan(int H, int B, Plan& p) {
+// More than one batch tile per cluster only when the batch has more tiles than the chip has clusters.  (The
+// forward kernel interleaves the tiles of a cluster, which hides a tile's hand-off under another tile's
+// compute -- 9 % faster than stepping them in lockstep at B = 1024 -- but two interleaved tiles on half the
+// CUs are still slower than one tile per cluster on all of them: 4.5 vs 3.4 us per step at B = 512.)
+bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   int US, KS;
   switch (H) {
     case 16: US = 16; KS = 1; break;
@@ -794,7 +793,7 @@ bool make_plan(int H, int B, Plan& p) {
   const int cus = tb_num_cus();
   const int max_clusters = cus / p.NCL > 0 ? cus / p.NCL : 1;
   int MT = 1;
-  const int mt_cap = (H >= 512) ? 1 : ((H >= 256 || H == 64) ? 2 : 4);
+  const int mt_cap = fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 512) ? 1 : ((H >= 256 || H == 64) ? 2 : 4));
   while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters) MT *= 2;
   p.MT = MT;
   p.rows_per_cluster = 16 * MT;
@@ -843,7 +842,7 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   FWD_CASE(256, 32, 2, 1); FWD_CASE(256, 32, 2, 2);
-  FWD_CASE(512, 16, 4, 1);
+  FWD_CASE(512, 16, 4, 1); FWD_CASE(512, 16, 4, 2);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }
 
@@ -915,7 +914,7 @@ int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
 size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
   (void)T;
   Plan p;
-  if (!make_plan(H, B, p)) return 0;
+  if (!make_plan(H, B, p, backward == 0)) return 0;
   return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
 }
 
@@ -932,7 +931,7 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   if (!x || !w_ih || !w_hh || !y || !gates || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
   if (train && !cstash) return tb_set_error(TB_ERR_ARG, "lstm_fwd: train needs a cell stash");
   Plan p;
-  if (!make_plan(H, B, p))
+  if (!make_plan(H, B, p, true))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d not supported (16,32,64,128,256,512)", H);
   Carve c;
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
