@@ -155,6 +155,28 @@ template <int AUX>
 __device__ __forceinline__ void stg4(__amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(float_off * 4), 0, AUX);
 }
+// N = 4, 2 or 1 consecutive floats per lane (the first N elements of an f32x4)
+template <int N, int AUX>
+__device__ __forceinline__ f32x4 ldgn(__amdgpu_buffer_rsrc_t r, long float_off) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (N == 4) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(float_off * 4), 0, AUX));
+  else if (N == 2) {
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(float_off * 4), 0, AUX);
+    v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]);
+  } else v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)(float_off * 4), 0, AUX));
+  return v;
+}
+template <int N, int AUX>
+__device__ __forceinline__ void stgn(__amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
+  if (N == 4) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)(float_off * 4), 0, AUX);
+  else if (N == 2) __builtin_amdgcn_raw_buffer_store_b64((u32x2){__float_as_uint(v[0]), __float_as_uint(v[1])}, r, (int)(float_off * 4), 0, AUX);
+  else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), r, (int)(float_off * 4), 0, AUX);
+}
+template <int N>
+__device__ __forceinline__ void stxn(bool same_l2, __amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
+  if (same_l2) stgn<N, 0>(r, float_off, v);
+  else stgn<N, kSC1>(r, float_off, v);
+}
 // exchange store: plain when the cluster shares one L2, write-through otherwise
 __device__ __forceinline__ void stx4(bool same_l2, __amdgpu_buffer_rsrc_t r, long float_off, f32x4 v) {
   if (same_l2) stg4<0>(r, float_off, v);
@@ -173,21 +195,25 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NKS = KPER / 32;        // 32-deep MFMA k-steps per wave
   constexpr int LDH = HK + 8;           // LDS row stride of the h tile (bf16 elements; 16-byte pad)
   constexpr int NACT = NUG * KS;        // waves doing MFMA work
-  constexpr int RED = (KS - 1) * NUG * 4 * 256;        // floats of k-split scratch (one tile at a time)
-  // exchange (NCL > 1): waves [0, NUG) finish the gates and publish, waves [NUG, 4) pull
-  constexpr int NPW = NCL > 1 ? 4 - NUG : 1;            // puller waves
-  constexpr int NPP = (NCL + NPW - 1) / NPW;            // producers per puller wave
+  // Every active wave finishes part of its unit group: the KS waves that split the k range of a unit
+  // group each take UPW = 4 / KS of a lane's 4 units (they swap the matching parts of their partial
+  // sums through LDS), so gate math, publish and pull are spread over all the waves of the workgroup.
+  constexpr int UPW = 4 / KS;
+  constexpr int RED = KS > 1 ? NUG * KS * KS * 256 * UPW : 0;   // floats of k-split scratch: [ug][dst][src][lane][4 gates][UPW]
+  // exchange (NCL > 1): wave w pulls the slices of producers m = w, w + 4, ...
+  constexpr int NPW = 4;
+  constexpr int NPP = (NCL + NPW - 1) / NPW;            // producers per wave
   constexpr int LPP = 16 * (US / 4) / 64;               // 16-byte loads per lane per producer (one 16-row tile)
   constexpr int NLD = NPP * LPP;                        // loads per lane per step
   constexpr int RS = MT * 16 * H;                       // floats per ring slot
-  static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0, "bad config");
-  static_assert(NCL == 1 || (NUG < 4 && (16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
+  static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0 && (KS == 1 || KS == 2 || KS == 4), "bad config");
+  static_assert(NCL == 1 || (NACT == 4 && (16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // h_{t-1} tile as split bf16 (hi, lo): [MT*16 rows][LDH], one ds_read_b128 per MFMA B operand
   unsigned short* hiL = reinterpret_cast<unsigned short*>(smem);
   unsigned short* loL = hiL + MT * 16 * LDH;
-  float* red = smem + MT * 16 * LDH;                   // [NUG][KS-1][4][64][4]
+  float* red = smem + MT * 16 * LDH;                   // [NUG][KS dst][KS src][64 lanes][4 gates][UPW]
   int* s_dead = reinterpret_cast<int*>(red + RED);
   int* s_word = s_dead + 1;
 
@@ -197,9 +223,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   cluster_decode(NCL, cl, j);
   const bool active = wave < NACT;
   const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
-  const bool fin = active && kp == 0;                  // this wave finishes the gates of its unit group
   const int uw = j * US + ug * 16 + col;               // W_hh row (per gate) this lane feeds to the MFMA
-  const int u0 = j * US + ug * 16 + q * 4;             // first of the 4 hidden units this lane finishes
+  const int u0 = j * US + ug * 16 + q * 4 + kp * UPW;  // first of the UPW hidden units this lane finishes
   const int b0 = a.b_begin + cl * 16 * MT;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
@@ -229,13 +254,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       }
       tb_split8(v0, v1, whi[g][s], wlo[g][s]);
     }
-  f32x4 c[MT], pre[MT][4];
+  float c[MT][UPW], pre[MT][4][UPW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    c[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      pre[mt][g] = fin ? ldg4<0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = active ? ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) pre[mt][g][u] = v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) c[mt][u] = 0.f;
   }
   bool same_l2 = false;
   if (NCL > 1) {
@@ -246,6 +275,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     __syncthreads();
   }
 
+  // the first pre-activations are complete before the loop (see the note at the prefetch wait below):
+  // otherwise the loop-carried `pre` counts as pending and the gate math starts with a vmcnt(0)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(pre[mt][g][u]));
   STAMP_DECL;
 #ifdef TB_STAMPS
   stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
@@ -265,18 +302,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       const int mt = x;
       STAMP(0);
       // (A) every consumer has read h_mt(t-2) (it published h_mt(t-1) after that, and our pull of
-      // h_mt(t-1) is complete): re-arm this member's slice of that slot, which is written next at step t+1
-      if (NCL > 1 && fin && t >= 2) {
+      // h_mt(t-1) is complete): re-arm this wave's part of that slot, which is written next at step t+1
+      if (NCL > 1 && t >= 2) {
         const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
-        stx4(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
+        stxn<UPW>(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
       }
-      // next step's pre-activations of this tile: independent of the recurrence.  Issued HERE, where no
-      // hand-off load of these waves follows: loads return in order, so an HBM miss issued just before a
-      // poll holds the poll and the pull behind it (measured: +2000 cycles per step)
-      f32x4 nxt[4];
-      if (t + 1 < T && fin) {
+      // next step's pre-activations of this tile: independent of the recurrence.  Issued HERE, a whole MFMA
+      // + gate phase before the next hand-off load of this wave: loads return in order, so an HBM miss
+      // issued just before a poll holds the poll and the pull behind it (measured: +2000 cycles per step)
+      float nxt[4][UPW];
+      if (t + 1 < T && active) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nxt[g] = ldg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
+#pragma unroll
+          for (int u = 0; u < UPW; ++u) nxt[g][u] = v[u];
+        }
       }
       // (B) (W_hh . h_{t-1}^T) on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
       f32x4 acc[4];
@@ -296,48 +337,85 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc[g], 0, 0, 0);
         }
-        if (KS > 1 && kp > 0) {
+        if (KS > 1) {   // hand every other k-part wave of this unit group the partial sums of ITS units
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(red + (((ug * (KS - 1) + kp - 1) * 4 + g) * 64 + lane) * 4) = acc[g];
+          for (int d = 0; d < KS; ++d) {
+            if (d == kp) continue;
+            float* dst = red + (size_t)(((ug * KS + d) * KS + kp) * 64 + lane) * 4 * UPW;
+            if (UPW == 2) {
+              *reinterpret_cast<f32x4*>(dst) = (f32x4){acc[0][d * 2], acc[0][d * 2 + 1], acc[1][d * 2], acc[1][d * 2 + 1]};
+              *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){acc[2][d * 2], acc[2][d * 2 + 1], acc[3][d * 2], acc[3][d * 2 + 1]};
+            } else {
+              *reinterpret_cast<f32x4*>(dst) = (f32x4){acc[0][d], acc[1][d], acc[2][d], acc[3][d]};
+            }
+          }
         }
       }
       STAMP(1);
       __syncthreads();   // all reads of this tile's h done; k-split partials visible
       STAMP(2);
-      // which tile / step the puller waves fetch in this phase (for the MFMA of the next phase)
+      // which tile / step is pulled in this phase (for the MFMA of the next phase)
       const int pt = (x + 1 < MT) ? x + 1 : 0;
       const int ps = (x + 1 < MT) ? t - 1 : t;
       const bool pull = NCL > 1 && ps >= 0 && ps + 1 < T;
-      if (fin) {
-        // (C) gate math, state update, h into LDS, the ring and y -- 4 consecutive units of one batch row per lane
-        f32x4 st[4], hn, hx, z[4];
+      float st[4][UPW], hn[UPW];
+      if (active) {
+        // (C) gate math, state update, h into LDS and the ring -- UPW consecutive units of one batch row per lane
+        float z[4][UPW];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          z[g] = acc[g] + pre[mt][g];
-          if (KS > 1 && t > 0) {
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int p2 = 0; p2 < KS - 1; ++p2)
-              z[g] += *reinterpret_cast<const f32x4*>(red + (((ug * (KS - 1) + p2) * 4 + g) * 64 + lane) * 4);
+          for (int u = 0; u < UPW; ++u) z[g][u] = acc[g][kp * UPW + u] + pre[mt][g][u];
+        if (KS > 1 && t > 0) {
+#pragma unroll
+          for (int sr = 0; sr < KS; ++sr) {
+            if (sr == kp) continue;
+            const float* src = red + (size_t)(((ug * KS + kp) * KS + sr) * 64 + lane) * 4 * UPW;
+            if (UPW == 2) {
+              const f32x4 p0 = *reinterpret_cast<const f32x4*>(src), p1 = *reinterpret_cast<const f32x4*>(src + 4);
+              z[0][0] += p0[0]; z[0][1] += p0[1]; z[1][0] += p0[2]; z[1][1] += p0[3];
+              z[2][0] += p1[0]; z[2][1] += p1[1]; z[3][0] += p1[2]; z[3][1] += p1[3];
+            } else {
+              const f32x4 p0 = *reinterpret_cast<const f32x4*>(src);
+              z[0][0] += p0[0]; z[1][0] += p0[1]; z[2][0] += p0[2]; z[3][0] += p0[3];
+            }
           }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float ig = fsig(z[0][r]), fg = fsig(z[1][r]), gg = ftanh(z[2][r]), og = fsig(z[3][r]);
+        for (int u = 0; u < UPW; ++u) {
+          const float ig = fsig(z[0][u]), fg = fsig(z[1][u]), gg = ftanh(z[2][u]), og = fsig(z[3][u]);
           // explicit fma: left to -ffp-contract the compiler picks either product, differently per instantiation
-          const float cn = __builtin_fmaf(fg, c[mt][r], ig * gg);
-          c[mt][r] = cn;
-          hn[r] = og * ftanh(cn);
-          st[0][r] = ig; st[1][r] = fg; st[2][r] = gg; st[3][r] = og;
+          const float cn = __builtin_fmaf(fg, c[mt][u], ig * gg);
+          c[mt][u] = cn;
+          hn[u] = og * ftanh(cn);
+          st[0][u] = ig; st[1][u] = fg; st[2][u] = gg; st[3][u] = og;
         }
-        u32x2 sh, sl;
-        tb_split4(hn, sh, sl);
-        *reinterpret_cast<u32x2*>(hiL + (mt * 16 + col) * LDH + u0) = sh;
-        *reinterpret_cast<u32x2*>(loL + (mt * 16 + col) * LDH + u0) = sl;
-        // the ring carries h already split, one {hi:16 | lo:16} word per element: the consumers only
-        // regroup the halves (2 v_perm per pair) instead of splitting again
-        hx = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
-                                              __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
+        // h_t of these units: split into bf16 hi / lo for the LDS tile; the ring carries them as one
+        // {hi:16 | lo:16} word per element, so the consumers only regroup the halves
+        unsigned short* ph = hiL + (mt * 16 + col) * LDH + u0;
+        unsigned short* pl = loL + (mt * 16 + col) * LDH + u0;
+        f32x4 hx = {0.f, 0.f, 0.f, 0.f};
+        if (UPW == 4) {
+          u32x2 sh, sl;
+          tb_split4((f32x4){hn[0], hn[1], hn[2], hn[3]}, sh, sl);
+          *reinterpret_cast<u32x2*>(ph) = sh;
+          *reinterpret_cast<u32x2*>(pl) = sl;
+          hx = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
+                                                __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
+        } else if (UPW == 2) {
+          unsigned sh, sl;
+          tb_split2(hn[0], hn[1], sh, sl);
+          *reinterpret_cast<unsigned*>(ph) = sh;
+          *reinterpret_cast<unsigned*>(pl) = sl;
+          hx[0] = __uint_as_float(__builtin_amdgcn_perm(sh, sl, 0x05040100u));
+          hx[1] = __uint_as_float(__builtin_amdgcn_perm(sh, sl, 0x07060302u));
+        } else {
+          unsigned sh, sl;
+          tb_split2(hn[0], 0.f, sh, sl);
+          *ph = (unsigned short)(sh & 0xFFFFu);
+          *pl = (unsigned short)(sl & 0xFFFFu);
+          hx[0] = __uint_as_float((sh << 16) | (sl & 0xFFFFu));
+        }
         if (NCL > 1 && t + 1 < T) {
           // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
           // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
@@ -345,28 +423,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           STAMP(5);
           asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           STAMP(6);
-          stx4(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
+          stxn<UPW>(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
         }
-        stg4<0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, hn);
-        STAMP(3);
-        if (a.train) {   // BPTT stash: activated gates over P in place, cell state
-#pragma unroll
-          for (int g = 0; g < 4; ++g) stg4<0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, st[g]);
-          stg4<0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, c[mt]);
-        }
-        STAMP(4);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[mt][g] = nxt[g];
-      } else if (pull) {
-        // (D) puller waves: the other members' slices of h_pt(ps) from the ring into the LDS tile.  The
-        // ring is sentinel-armed and every slot word is written once per turn, so the data is its own ready
-        // flag: poll the last piece each storing wave of each of my producers writes, then pull, then
-        // re-pull whatever is still armed.  These waves issue no other memory traffic, so nothing queues
-        // before the hand-off in their memory counters.
-        const int pw = wave - NUG;
+      }
+      STAMP(3);
+      if (pull) {
+        // (D) the other members' slices of h_pt(ps) from the ring into the LDS tile; wave w takes producers
+        // w, w+4, ...  The ring is sentinel-armed and every slot word is written once per turn, so the data
+        // is its own ready flag: poll the last piece of each unit group of each of my producers (a piece is
+        // complete when none of its 4 words is armed: its parts come from different waves), then pull, then
+        // re-pull whatever is still armed.  Only the ring store above precedes these loads in this wave's
+        // memory queue: y and the stash are stored after the pull.
         const long sbase = (long)(ps % 3) * RS + (long)pt * 16 * H;
         if (lane < NPP * NUG) {
-          const int m = pw + (lane / NUG) * NPW;
+          const int m = wave + (lane / NUG) * NPW;
           if (m < NCL && m != j) {
             const int voff = (int)((sbase + (long)15 * H + m * US + (lane % NUG) * 16 + 12) * 4);
             const unsigned long long t0 = wall_clock64();
@@ -381,12 +451,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
             }
           }
         }
-        STAMP(5);
+        STAMP(4);
         u32x4 buf[NLD];
         unsigned pend = 0;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
-          const int m = pw + (n / LPP) * NPW;
+          const int m = wave + (n / LPP) * NPW;
           if (m < NCL && m != j) pend |= 1u << n;
         }
         unsigned it = 0;
@@ -395,7 +465,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           asm volatile("" ::: "memory");
 #pragma unroll
           for (int n = 0; n < NLD; ++n) {
-            const int m = pw + (n / LPP) * NPW;
+            const int m = wave + (n / LPP) * NPW;
             const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
             if ((pend >> n) & 1u) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
           }
@@ -415,7 +485,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         STAMP(7);
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
-          const int m = pw + (n / LPP) * NPW;
+          const int m = wave + (n / LPP) * NPW;
           const int pc = (n % LPP) * 64 + lane, row = pt * 16 + pc / (US / 4), c4 = pc % (US / 4);
           if (m < NCL && m != j) {
             const u32x2 sh = {__builtin_amdgcn_perm(buf[n][1], buf[n][0], 0x07060302u), __builtin_amdgcn_perm(buf[n][3], buf[n][2], 0x07060302u)};
@@ -424,6 +494,37 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
             *reinterpret_cast<u32x2*>(loL + row * LDH + m * US + c4 * 4) = sl;
           }
         }
+      }
+      // Make the wait for the prefetched pre-activations fall HERE, where everything older than the pull
+      // has long completed: left alone, the compiler waits for them with vmcnt(0) at their first use in
+      // the next phase's gate math -- behind the prefetch loads issued just before it (HBM latency, ~1200
+      // cycles on the critical path of every step).
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(nxt[g][u]));
+      if (active) {
+        // (E) y for the next layer and the BPTT stash (activated gates over P in place, cell state): after
+        // the pull, so that no HBM store sits in front of the hand-off loads
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < UPW; ++u) v[u] = hn[u];
+        stgn<UPW, 0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, v);
+        if (a.train) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int u = 0; u < UPW; ++u) v[u] = st[g][u];
+            stgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, v);
+          }
+#pragma unroll
+          for (int u = 0; u < UPW; ++u) v[u] = c[mt][u];
+          stgn<UPW, 0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, v);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int u = 0; u < UPW; ++u) pre[mt][g][u] = nxt[g][u];
       }
       STAMP(8);
       __syncthreads();   // the pulled tile is complete for its MFMA in the next phase
@@ -541,6 +642,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   } else {
     __syncthreads();
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the first step's stash is in registers before the loop (loop-carried state)
 
   STAMP_DECL;
   for (int t = T - 1; t >= 0; --t) {
@@ -717,7 +819,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             // gets there only after consuming this member's partial of step t-2, which is stored
             // after the barrier that follows the NEXT step's copy of this wait -- and that wait
             // covers these stores.  So the re-arm always lands before the next write.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the builtin, not inline asm: the compiler then KNOWS every earlier load has landed -- the
+            // prefetched stash of the next step included -- and does not start the next step's gate math
+            // with a vmcnt(0) behind these re-arm stores)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
             const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
 #pragma unroll
             for (int m = 0; m < NCL; ++m)
@@ -800,7 +905,7 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   p.clusters_per_launch = max_clusters;
   const int NUG = US / 16;
   const int HK = H < 32 ? 32 : H;
-  p.lds_fwd = ((size_t)MT * 16 * (HK + 8) + (size_t)(KS - 1) * NUG * MT * 4 * 256) * 4 + 16;
+  p.lds_fwd = ((size_t)MT * 16 * (HK + 8) + (size_t)(KS > 1 ? NUG * KS * KS * 256 * (4 / KS) : 0)) * 4 + 16;
   p.lds_bwd = ((size_t)MT * 16 * (4 * US + 8) + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
   return true;
 }

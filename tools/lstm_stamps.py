@@ -18,7 +18,7 @@ from timeband_amd import ops  # noqa: E402
 cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.startswith("--")] or [(512, 128, 32, 256), (1024, 128, 32, 256), (512, 128, 36, 64)]
 lib = _lib.load()
 dev = torch.device("cuda", 0)
-FWD = ["top/rearm", "mfma", "sync1", "gates+pub", "pf+stash", "poll", "-", "pull", "split+lds", "sync3", "same_l2*1000", "xcc_reg"]
+FWD = ["top/rearm/pf", "mfma", "sync1", "publish", "poll", "gates", "vm wait", "pull", "lds+y/stash st", "sync3", "same_l2*1000", "xcc_reg"]
 BWD = ["top", "gate grads+lds+pf", "sync", "mfma+X st", "sync", "dgates st", "poll(w0)", "sync", "reduce-scatter"]
 for (B, T, In, H) in cases:
     g = torch.Generator(device="cpu").manual_seed(1)
