@@ -182,6 +182,13 @@ __device__ __forceinline__ void stx4(bool same_l2, __amdgpu_buffer_rsrc_t r, lon
   if (same_l2) stg4<0>(r, float_off, v);
   else stg4<kSC1>(r, float_off, v);
 }
+template <int N>
+__device__ __forceinline__ bool armedn(f32x4 v) {   // any of the first N words still the sentinel
+  bool r = __float_as_uint(v[0]) == kSentinel;
+  if (N >= 2) r = r || __float_as_uint(v[1]) == kSentinel;
+  if (N >= 4) r = r || __float_as_uint(v[2]) == kSentinel || __float_as_uint(v[3]) == kSentinel;
+  return r;
+}
 __device__ __forceinline__ bool armed(u32x4 v) {
   return v[0] == kSentinel || v[1] == kSentinel || v[2] == kSentinel || v[3] == kSentinel;
 }
@@ -358,6 +365,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       const int pt = (x + 1 < MT) ? x + 1 : 0;
       const int ps = (x + 1 < MT) ? t - 1 : t;
       const bool pull = NCL > 1 && ps >= 0 && ps + 1 < T;
+      const long sbase = (long)(ps % 3) * RS + (long)pt * 16 * H;
+      // With several tiles per cluster the slices pulled in this phase were published a whole phase ago:
+      // their loads are issued BEFORE the gate math and checked after it (what is still armed is re-pulled)
+      u32x4 buf[NLD];
+      if (MT > 1 && pull) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+          const int m = wave + (n / LPP) * NPW;
+          const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
+          if (m < NCL && m != j) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
+        }
+      }
       float st[4][UPW], hn[UPW];
       if (active) {
         // (C) gate math, state update, h into LDS and the ring -- UPW consecutive units of one batch row per lane
@@ -419,9 +438,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         if (NCL > 1 && t + 1 < T) {
           // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
           // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
-          // of a wave complete in order: all but the 4 prefetch loads issued after the re-arm.
+          // of a wave complete in order: all but the 4 prefetch loads (and, with MT > 1, the NLD early pull
+          // loads) issued after the re-arm.
           STAMP(5);
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          else if (NLD <= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else if (NLD <= 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
           STAMP(6);
           stxn<UPW>(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
         }
@@ -434,8 +457,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         // complete when none of its 4 words is armed: its parts come from different waves), then pull, then
         // re-pull whatever is still armed.  Only the ring store above precedes these loads in this wave's
         // memory queue: y and the stash are stored after the pull.
-        const long sbase = (long)(ps % 3) * RS + (long)pt * 16 * H;
-        if (lane < NPP * NUG) {
+        if (MT == 1 && lane < NPP * NUG) {
           const int m = wave + (lane / NUG) * NPW;
           if (m < NCL && m != j) {
             const int voff = (int)((sbase + (long)15 * H + m * US + (lane % NUG) * 16 + 12) * 4);
@@ -452,12 +474,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           }
         }
         STAMP(4);
-        u32x4 buf[NLD];
         unsigned pend = 0;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
           const int m = wave + (n / LPP) * NPW;
-          if (m < NCL && m != j) pend |= 1u << n;
+          if (m < NCL && m != j && (MT == 1 || armed(buf[n]))) pend |= 1u << n;
         }
         unsigned it = 0;
         unsigned long long t0 = 0;
@@ -560,10 +581,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int LDG = KD + 8;                      // LDS row stride of the dgates tile (bf16 elements)
   constexpr int NTW = H >= 64 ? H / 64 : 1;        // 16-col output tiles per wave
   constexpr int NAW = H >= 64 ? 4 : H / 16;        // waves doing MFMA work
-  constexpr int QPR = US / 4;                      // unit quads per row
-  constexpr int NE = MT * 16 * QPR;                // (row, unit quad) items of the tile
+  constexpr int UI = US / 16;                      // units per elementwise item: 16 items per row, so that
+  constexpr int QPR = US / UI;                     // one 16-row tile is exactly 256 items -- every thread works
+  constexpr int NE = MT * 16 * QPR;                // (row, unit group) items of the tile
   constexpr int NQ = (NE + 255) / 256;             // items per thread
   constexpr int LDH = H + 4;                       // dhL row stride (floats)
+  static_assert(UI == 1 || UI == 2 || UI == 4, "US must be 16, 32 or 64");
   static_assert((256 % QPR) == 0 && (NE % 256 == 0 || NE < 256), "bad config");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -612,9 +635,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       }
       tb_split8(v0, v1, wbh[nt][s], wbl[nt][s]);
     }
-  // elementwise items: e = tid + 256*n -> unit quad qd (constant per thread), row, mt
+  // elementwise items: e = tid + 256*n -> unit group qd (constant per thread) of UI units, row, mt
+  // (f32x4 containers, the first UI elements in use)
   const int qd = tid % QPR;
-  const int ul0 = qd * 4, uabs0 = j * US + ul0;
+  const int ul0 = qd * UI, uabs0 = j * US + ul0;
   f32x4 dc[NQ], dhrec[NQ], dbacc[4];
   // stash of the current step (prefetched one step ahead): i, f, g, o, c_t, c_{t-1}, dy
   f32x4 cur[NQ][7];
@@ -629,10 +653,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     const long rr = mt * 16 + row;
     const bool ok = e < NE;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) cur[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(T - 1) * 4 * H + g * H + uabs0) : zero4;
-    cur[n][4] = ok ? ldg4<0>(rC, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
-    cur[n][5] = (ok && T > 1) ? ldg4<0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
-    cur[n][6] = ok ? ldg4<0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
+    for (int g = 0; g < 4; ++g) cur[n][g] = ok ? ldgn<UI, 0>(rG, rr * rowG + (long)(T - 1) * 4 * H + g * H + uabs0) : zero4;
+    cur[n][4] = ok ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
+    cur[n][5] = (ok && T > 1) ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
+    cur[n][6] = ok ? ldgn<UI, 0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
   }
   bool same_l2 = false;
   if (NCL > 1) {
@@ -655,7 +679,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       const int e = tid + 256 * n;
       const int row = (e / QPR) & 15, mt = e / (16 * QPR);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int g = 0; g < 4; ++g) dgv[n][g] = zero4;
+#pragma unroll
+      for (int r = 0; r < UI; ++r) {
         const float ig = cur[n][0][r], fg = cur[n][1][r], gg = cur[n][2][r], og = cur[n][3][r];
         const float dh = cur[n][6][r] + dhrec[n][r];
         const float tc = ftanh(cur[n][4][r]);
@@ -671,10 +697,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           dbacc[g] += dgv[n][g];
-          u32x2 sh, sl;
-          tb_split4(dgv[n][g], sh, sl);
-          *reinterpret_cast<u32x2*>(dgHi + (mt * 16 + row) * LDG + g * US + ul0) = sh;
-          *reinterpret_cast<u32x2*>(dgLo + (mt * 16 + row) * LDG + g * US + ul0) = sl;
+          unsigned short* ph = dgHi + (mt * 16 + row) * LDG + g * US + ul0;
+          unsigned short* pl = dgLo + (mt * 16 + row) * LDG + g * US + ul0;
+          if (UI == 4) {
+            u32x2 sh, sl;
+            tb_split4(dgv[n][g], sh, sl);
+            *reinterpret_cast<u32x2*>(ph) = sh;
+            *reinterpret_cast<u32x2*>(pl) = sl;
+          } else {
+            unsigned sh, sl;
+            tb_split2(dgv[n][g][0], dgv[n][g][1], sh, sl);
+            if (UI == 2) {
+              *reinterpret_cast<unsigned*>(ph) = sh;
+              *reinterpret_cast<unsigned*>(pl) = sl;
+            } else {
+              *ph = (unsigned short)(sh & 0xFFFFu);
+              *pl = (unsigned short)(sl & 0xFFFFu);
+            }
+          }
         }
       }
     }
@@ -688,9 +728,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         const long rr = mt * 16 + row;
         const bool ok = e < NE;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldg4<0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
-        nx[n][4] = (ok && t > 1) ? ldg4<0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
-        nx[n][5] = ok ? ldg4<0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
+        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldgn<UI, 0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
+        nx[n][4] = (ok && t > 1) ? ldgn<UI, 0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
+        nx[n][5] = ok ? ldgn<UI, 0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
       }
     }
     STAMP(1);
@@ -740,7 +780,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       const int row = (e / QPR) & 15, mt = e / (16 * QPR);
       if (e < NE) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) stg4<0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
+        for (int g = 0; g < 4; ++g) stgn<UI, 0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
       }
     }
     STAMP(5);
@@ -776,17 +816,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       const int e = tid + 256 * n;
       const int row = (e / QPR) & 15, mt = e / (16 * QPR);
       if (e < NE) {
-        f32x4 s = *reinterpret_cast<const f32x4*>(dhL + (mt * 16 + row) * LDH + uabs0);
+        f32x4 s = zero4;
+#pragma unroll
+        for (int r = 0; r < UI; ++r) s[r] = dhL[(mt * 16 + row) * LDH + uabs0 + r];
         if (NCL > 1) {
           const long base = (long)par * XSLAB + ((long)(j * NCL) * MT * 16 + mt * 16 + row) * US + ul0;
           f32x4 v[NCL];
 #pragma unroll
-          for (int m = 0; m < NCL; ++m) v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
+          for (int m = 0; m < NCL; ++m) v[m] = ldgn<UI, kSC1>(rX, base + (long)m * MT * 16 * US);
           {
             unsigned pend = 0;
 #pragma unroll
             for (int m = 0; m < NCL; ++m)
-              if (m != j && armed(__builtin_bit_cast(u32x4, v[m]))) pend |= 1u << m;
+              if (m != j && armedn<UI>(v[m])) pend |= 1u << m;
             unsigned it = 0;
             unsigned long long t0 = 0;
             while (pend) {   // rare: a piece behind the polled one
@@ -794,8 +836,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
               for (int m = 0; m < NCL; ++m)
                 if ((pend >> m) & 1u) {
-                  v[m] = ldg4<kSC1>(rX, base + (long)m * MT * 16 * US);
-                  if (!armed(__builtin_bit_cast(u32x4, v[m]))) pend &= ~(1u << m);
+                  v[m] = ldgn<UI, kSC1>(rX, base + (long)m * MT * 16 * US);
+                  if (!armedn<UI>(v[m])) pend &= ~(1u << m);
                 }
               if (pend && (++it & 255u) == 0) {
                 const unsigned long long now = wall_clock64();
@@ -812,7 +854,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
           for (int m = 0; m < NCL; ++m) {
             const bool other = m != j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] += other ? v[m][r] : 0.f;
+            for (int r = 0; r < UI; ++r) s[r] += other ? v[m][r] : 0.f;
           }
           {
             // Re-arm what was consumed.  The slab of step t is written again at step t-3; its writer
@@ -826,7 +868,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
 #pragma unroll
             for (int m = 0; m < NCL; ++m)
-              if (m != j) stx4(same_l2, rX, base + (long)m * MT * 16 * US, arm);
+              if (m != j) stxn<UI>(same_l2, rX, base + (long)m * MT * 16 * US, arm);
           }
         }
         dhrec[n] = s;
@@ -842,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     }
   }
   STAMP_FLUSH(1, cl, j);
-  // bias grads of this cluster: reduce the threads that share a unit quad, one partial row per cluster
+  // bias grads of this cluster: reduce the threads that share a unit group, one partial row per cluster
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dbL + tid * 16 + g * 4) = dbacc[g];
@@ -851,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     const int g = tid / US, ul = tid % US;
     constexpr int NTH = NE < 256 ? NE : 256;
     float s = 0.f;
-    for (int th = ul / 4; th < NTH; th += QPR) s += dbL[th * 16 + g * 4 + (ul & 3)];
+    for (int th = ul / UI; th < NTH; th += QPR) s += dbL[th * 16 + g * 4 + (ul % UI)];
     a.dbpart[(size_t)(a.cl_begin + cl) * 4 * H + g * H + j * US + ul] = s;
   }
 }
