@@ -940,7 +940,12 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   const int cus = tb_num_cus();
   const int max_clusters = cus / p.NCL > 0 ? cus / p.NCL : 1;
   int MT = 1;
-  const int mt_cap = fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 512) ? 1 : ((H >= 256 || H == 64) ? 2 : 4));
+  // Tiles per cluster.  Two clustered kernels may run at once (the trainer overlaps streams), and a cluster
+  // only makes progress with all its workgroups resident: every launch is at most one workgroup per CU, and
+  // the variants that can meet on a full-size batch stay within half a SIMD's registers (256), so two such
+  // launches always fit side by side.  BPTT at H=256 with two tiles needs 288 and is no faster than two
+  // one-tile launches (6.0 vs 2 x 2.9 us/step), hence the cap of 1 there.
+  const int mt_cap = fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4));
   while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters) MT *= 2;
   p.MT = MT;
   p.rows_per_cluster = 16 * MT;
