@@ -385,6 +385,65 @@ def train_iteration(st, x, y, xc=None, yc=None, training=True, rec=None):
 
 
 # --------------------------------------------------------------------------------------
+# Gen-B schedule.  source/core.py:64-130 with source/losses.py:86-105
+# --------------------------------------------------------------------------------------
+class GenBState:
+    """core.py:64-70: Adam(D), Adam(G) and ONE RMSprop over D that persists across critic calls."""
+
+    def __init__(self, pD, pG, n_layers=1, lr_D=2e-4, lr_G=2e-4, losses=None):
+        self.pD = {k: np.array(v, F32) for k, v in pD.items()}
+        self.pG = {k: np.array(v, F32) for k, v in pG.items()}
+        self.L = n_layers
+        self.losses = losses or Losses()
+        self.adamD, self.adamG, self.rmsC = Adam(lr_D), Adam(lr_G), RMSprop(lr_D)
+
+
+def genb_critic_step(st, xc, yc, rec=None):
+    """core.py:74-89: LSGAN dis_loss (losses.py:99-105), one step of the persistent RMSprop."""
+    fake, _ = generator_fwd(st.pG, xc, st.L)
+    Dy, cDy = discriminator_fwd(st.pD, yc, st.L)
+    DGx, cDG = discriminator_fwd(st.pD, fake, st.L)
+    errC, dDy, dDGx, _ = st.losses.dis_loss(None, None, Dy, DGx)
+    gD = {}
+    discriminator_bwd(gD, dDy, cDy, need_dx=False)
+    discriminator_bwd(gD, dDGx, cDG, need_dx=False)
+    if rec is not None:
+        rec["errC"] = errC
+        rec["grad.netD"] = {k: v.copy() for k, v in gD.items()}
+    st.rmsC.step(st.pD, gD)
+    return errC
+
+
+def genb_iteration(st, x, y, training=True, rec=None):
+    """core.py:98-130: D step, then a G step whose gradients start from zero (optimG.zero_grad at
+    :122 -- unlike Gen-A, the D-phase pass through G does not reach the G update)."""
+    fake, _ = generator_fwd(st.pG, x, st.L)
+    Dy, cDy = discriminator_fwd(st.pD, y, st.L)
+    DGx, cDG = discriminator_fwd(st.pD, fake, st.L)
+    errD, dDy, dDGx, _ = st.losses.dis_loss(None, None, Dy, DGx)
+    if training:
+        gD = {}
+        discriminator_bwd(gD, dDy, cDy, need_dx=False)
+        discriminator_bwd(gD, dDGx, cDG, need_dx=False)
+        if rec is not None:
+            rec["errD"] = errD
+            rec["dphase.grad.netD"] = {k: v.copy() for k, v in gD.items()}
+        st.adamD.step(st.pD, gD)
+    fake, cG = generator_fwd(st.pG, x, st.L)
+    DGx, cDG = discriminator_fwd(st.pD, fake, st.L)
+    errG, dDGx, dpred = st.losses.gen_loss(y, fake, DGx)
+    if training:
+        gG, scratch = {}, {}
+        dfake = discriminator_bwd(scratch, dDGx, cDG, need_dx=True)
+        generator_bwd(gG, (dfake + dpred).astype(F32), cG)
+        if rec is not None:
+            rec["errG"] = errG
+            rec["gphase.grad.netG"] = {k: v.copy() for k, v in gG.items()}
+        st.adamG.step(st.pG, gG)
+    return fake
+
+
+# --------------------------------------------------------------------------------------
 # Dataset: normalise / windows / denormalise.  source/dataset.py
 # --------------------------------------------------------------------------------------
 def interpolate(a):
@@ -501,8 +560,8 @@ class Band:
 
 
 def adjust(variant, output, preds, masks, lower, upper, a, b):
-    """variant in {"trainer","cleaner","predictor"}: trainer.py:238-257, cleaner.py:130-149,
-    predictor.py:106-125.  `output` has len(preds)+1 rows and is updated in place."""
+    """variant in {"trainer","cleaner","predictor","genb"}: trainer.py:238-257, cleaner.py:130-149,
+    predictor.py:106-125, models.py:196-215.  `output` has len(preds)+1 rows and is updated in place."""
     for p in range(preds.shape[0]):
         value = output[p + 1]
         m = masks[p]
@@ -510,6 +569,12 @@ def adjust(variant, output, preds, masks, lower, upper, a, b):
             value = (1 - m) * value + m * (a * preds[p] + (1 - a) * output[p])
             lm = (value < lower[p]) * (1 - m)
             um = (value > upper[p]) * (1 - m)
+            value = (1 - lm) * value + lm * (b * preds[p] + (1 - b) * value)
+            value = (1 - um) * value + um * (b * preds[p] + (1 - b) * value)
+        elif variant == "genb":
+            lm = (value < lower[p]) * (1 - m)
+            um = (value > upper[p]) * (1 - m)
+            value = (1 - m) * value + m * (a * preds[p] + (1 - a) * output[p])
             value = (1 - lm) * value + lm * (b * preds[p] + (1 - b) * value)
             value = (1 - um) * value + um * (b * preds[p] + (1 - b) * value)
         elif variant == "cleaner":

@@ -1,0 +1,201 @@
+"""GPU: the Gen-B API (timeband_amd/models.py, losses.py, metrics.py, data.py, core.py) against what
+the reference's source/losses.py and source/metrics.py produced and the Gen-B schedule of
+source/core.py:64-130 driven with the reference's own loss object (tests/golden/genb.npz, made by
+tests/golden/make_golden_genb.py).  The band / adjust of source/models.py:173-215 cannot be run from
+the reference here (models.py needs structlog): it is checked against the oracle's restatement --
+parity unpinned for that one function beyond the Gen-A band goldens, which share its arithmetic."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sub(z, prefix):
+    prefix += "."
+    return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def grads_close(module, want, tol, what):
+    gmax = max(np.abs(v).max() for v in want.values())
+    for k, p in module.named_parameters():
+        err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
+        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
+
+
+def params_close(module, want, step, what):
+    nbad = ntot = 0
+    for k, v in module.state_dict().items():
+        d = np.abs(v.cpu().numpy().astype(np.float64) - want[k])
+        assert d.max() <= 2.1 * step, (what, k, d.max())
+        nbad += int((d > 0.05 * step).sum())
+        ntot += d.size
+    assert nbad / ntot < 1e-3, (what, nbad, ntot)
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(GOLDEN, "genb.npz"))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda", 0)
+
+
+def test_init_order_matches_reference(z, dev):
+    """TimebandModel draws D before G (models.py:145-158); seed 42 is the launcher's (launcher.py:9)."""
+    from timeband_amd.models import TimebandModel
+    from timeband_amd.utils.initiate import seeding
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    seeding(42)
+    m = TimebandModel(E, V, H, To, Tf, device=dev)
+    for tag, net in (("init.netD", m.netD), ("init.netG", m.netG)):
+        for k, v in net.state_dict().items():
+            assert np.array_equal(v.cpu().numpy(), z[f"{tag}.{k}"]), (tag, k)
+
+
+def test_gan_loss_modes(z, dev):
+    from timeband_amd.losses import GANLoss
+    for mode in ("vanilla", "lsgan", "wgangp"):
+        for real in (1, 0):
+            q = torch.tensor(z["gan.p"], device=dev).requires_grad_()
+            val = GANLoss(mode)(q, bool(real))
+            val.backward()
+            assert rel(val.item(), z[f"gan.{mode}.{real}.val"]) < 1e-5, (mode, real)
+            assert rel(q.grad.cpu().numpy(), z[f"gan.{mode}.{real}.grad"]) < 1e-5, (mode, real)
+
+
+def test_genb_schedule(z, dev):
+    """Timeband.critic (persistent RMSprop, LSGAN loss) and Timeband.iteration (D step, then a G step
+    from zeroed gradients) against the reference-driven run."""
+    from timeband_amd.core import Timeband
+    from timeband_amd.losses import TimebandLoss
+    from timeband_amd.metrics import TIMEBANDMetric
+    from timeband_amd.models import TimebandModel
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    lr = float(z["lr"])
+    l1, l2, gp = (float(v) for v in z["weights"])
+    T = lambda a: torch.tensor(a, device=dev)
+    core = Timeband.__new__(Timeband)          # the constructor reads a csv; the schedule does not
+    core.device, core.observed_len, core.forecast_len = dev, To, Tf
+    core.Model = TimebandModel(E, V, H, To, Tf, device=dev)
+    core.Model.netD.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netD").items()})
+    core.Model.netG.load_state_dict({k: torch.tensor(v) for k, v in sub(z, "init.netG").items()})
+    core.Losses = TimebandLoss(l1_weights=l1, l2_weights=l2, gp_weights=gp)
+    core.Metric = TIMEBANDMetric(device=dev)
+    core.init_optimizer(lr_D=lr, lr_G=lr)
+
+    class Draws:
+        def __init__(self):
+            self.k = 0
+
+        def get_random(self, trainset):
+            k, self.k = self.k, self.k + 1
+            return T(z[f"xc{k}"]), T(z[f"yc{k}"])
+
+    core.Data = Draws()
+    netD, netG = core.Model.netD, core.Model.netG
+    core.critic(None, 1)
+    grads_close(netD, sub(z, "critic0.grad.netD"), 1e-3, "critic0 grad D")
+    params_close(netD, sub(z, "critic0.after.netD"), 10 * lr, "D after critic 0")
+    core.critic(None, 1)                       # the SAME RMSprop: its square average carries over
+    grads_close(netD, sub(z, "critic1.grad.netD"), 1e-3, "critic1 grad D")
+    params_close(netD, sub(z, "critic1.after.netD"), 10 * lr, "D after critic 1")
+    core.Losses.init_loss()
+    for k in range(2):
+        fake = core.iteration(T(z[f"x{k}"]), T(z[f"y{k}"]), training=True)
+        assert rel(fake.cpu().numpy(), z[f"it{k}.fake_y"]) < 1e-4
+        grads_close(netG, sub(z, f"it{k}.gphase.grad.netG"), 1e-3, f"it{k} grad G")
+        params_close(netD, sub(z, f"it{k}.after.netD"), lr, f"D after it{k}")
+        params_close(netG, sub(z, f"it{k}.after.netG"), lr, f"G after it{k}")
+    log = core.Losses.loss(1)
+    assert list(log.keys()) == list(z["loss.keys"])
+    np.testing.assert_allclose([float(v) for v in log.values()], z["loss.values"], atol=1.5e-3)
+
+
+def test_metric_scoring(z, dev):
+    import pandas as pd
+    from timeband_amd.metrics import TIMEBANDMetric
+    m = TIMEBANDMetric(device=dev)
+    m.init_score()
+    got = m.scoring(pd.DataFrame(z["metric.true"]), z["metric.pred"], pd.DataFrame(z["metric.mask"]))
+    np.testing.assert_allclose(got, z["metric.out"], rtol=1e-9)
+    sc = m.score(0)
+    assert [sc["NME"], sc["NMAE"], sc["RMSE"]] == list(z["metric.score"])
+
+
+def test_predicts_and_adjust_vs_oracle(dev):
+    """models.py:173-215: 3*std band over the horizon history carried across batches, then the scan."""
+    from oracle import timeband_oracle as O
+    from timeband_amd.models import TimebandModel
+    V, E, To, Tf, H = 6, 8, 12, 7, 16
+    m = TimebandModel(E, V, H, To, Tf, device=dev, missing_gamma=0.2, anomaly_gamma=0.3)
+    band = O.Band(Tf, V, 3.0)
+    rng = np.random.default_rng(5)
+    for B in (4, 9, 2):
+        pred = rng.normal(size=(B, Tf, V)).astype(np.float32) * 4
+        med, lo, up = m.predicts(torch.tensor(pred, device=dev))
+        wmed, wlo, wup = band.predicts(pred.astype(np.float64))
+        np.testing.assert_allclose(med.cpu().numpy(), wmed, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lo.cpu().numpy(), wlo, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(up.cpu().numpy(), wup, rtol=1e-9, atol=1e-9)
+        n = B + Tf - 1
+        output = rng.normal(size=(n + 1, V)) * 6
+        masks = (rng.random((n, V)) < 0.3).astype(int)
+        want = O.adjust("genb", output.copy(), wmed, masks, wlo, wup, 0.2, 0.3)
+        got = m.adjust(output, med, masks, lo, up)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+
+
+def test_core_end_to_end_on_csv(dev, tmp_path):
+    """Timeband(...) on a csv in the origin/ target/ meta/ layout: data artefacts, critic, one train
+    pass, one validation pass, predict."""
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    from timeband_amd import synthetic
+    from timeband_amd.core import Timeband
+    from timeband_amd.utils.initiate import seeding
+    V, To, Tf, N = 3, 10, 5, 300
+    base = str(tmp_path)
+    # no missing values: Gen-B scores against the raw series with an all-zero mask (data.py:132-134 takes
+    # the mask after the forward/backward fill), so a NaN in the data would make its score NaN
+    synthetic.write_csv(os.path.join(base, "origin"), "all", N, V, seed=42, missing_rate=0.0)
+    seeding(42)
+    core = Timeband(datadir=base, filename="all", observed_len=To, forecast_len=Tf, l1_weights=1, l2_weights=1,
+                    gp_weights=1, hidden_dim=64, time_encode=["weekday", "day", "hour"],
+                    split_size=0.8, device=dev)
+    assert core.Data.decode_dims == V and core.Data.encode_dims == V + 3
+    frame = core.Data.init_dataset(index_s=0, index_e=None)
+    for f in (core.Data.target_path, core.Data.minmax_path, core.Data.missing_path):
+        assert os.path.exists(f), f
+    assert list(pd.read_csv(core.Data.minmax_path).columns) == ["Feats", "min", "max"]
+    trainset, validset = core.Data.prepare_trainset(frame)
+    assert trainset.shape() == (int(N * 0.8), To, V + 3) and trainset.shape("decode") == (int(N * 0.8), Tf, V)
+    assert len(trainset) + len(validset) == N - To - Tf + 1
+    x0, y0 = trainset[0]
+    assert x0.shape == (To, V + 3) and y0.shape == (Tf, V) and float(x0.abs().max()) <= 1.0 + 1e-6
+    core.init_optimizer(lr_D=2e-4, lr_G=2e-4)
+    before = core.Model.netG.state_dict()["lstm2.weight_hh_l0"].clone()
+    core.idx = core.observed_len
+    core.critic(trainset, 2)
+    train_score = core.train_step(DataLoader(trainset, batch_size=64), training=True)
+    valid_score = core.train_step(DataLoader(validset, batch_size=16))
+    assert np.isfinite(train_score) and np.isfinite(valid_score)
+    assert not torch.equal(core.Model.netG.state_dict()["lstm2.weight_hh_l0"], before)
+    assert core.is_best(valid_score) == (valid_score < 10.0)
+    sub_frame = pd.read_csv(core.Data.target_path, parse_dates=["Date"]).iloc[-To - Tf:]
+    predset = core.Data.prepare_predset(sub_frame)
+    outputs, bands = core.predict(DataLoader(predset))
+    assert list(outputs.columns) == [f"v{i}" for i in range(V)]
+    assert list(bands.columns) == [f"v{i}_lower" for i in range(V)] + [f"v{i}_upper" for i in range(V)]
+    assert len(outputs) == len(bands) == len(predset) + Tf - 1 + 1 and np.isfinite(outputs.to_numpy()).all()

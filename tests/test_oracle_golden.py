@@ -290,3 +290,53 @@ def test_torch_port_matches_reference(golden_dir, name):
     want = sub(z, "it2.gphase.after.netG")
     for k, v in G.state_dict().items():
         assert np.abs(v.numpy() - want[k]).max() < 1e-7, k
+
+
+# ---------------------------------------------------------------------------------------------
+# Gen-B (source/losses.py, source/metrics.py, schedule of source/core.py:64-130): genb.npz
+# ---------------------------------------------------------------------------------------------
+def test_genb_gan_loss_modes(golden_dir):
+    z = load(golden_dir, "genb.npz")
+    p = z["gan.p"]
+    for mode in ("vanilla", "lsgan", "wgangp"):
+        for real in (1, 0):
+            val, grad = O.gan_loss(p, bool(real), mode)
+            assert relerr(val, z[f"gan.{mode}.{real}.val"]) < 1e-6, (mode, real)
+            assert relerr(grad, z[f"gan.{mode}.{real}.grad"]) < 1e-6, (mode, real)
+
+
+def test_genb_schedule(golden_dir):
+    """Persistent-RMSprop critic with the LSGAN loss, D step, G step from zeroed gradients."""
+    z = load(golden_dir, "genb.npz")
+    V, E, To, Tf, H, L, B = z["meta"]
+    lr = float(z["lr"])
+    l1, l2, gp = z["weights"]
+    st = O.GenBState(sub(z, "init.netD"), sub(z, "init.netG"), int(L), lr, lr, O.Losses(l1, l2, gp))
+    for k in range(2):
+        rec = {}
+        O.genb_critic_step(st, z[f"xc{k}"], z[f"yc{k}"], rec)
+        assert relerr(rec["errC"], z[f"critic{k}.errC"]) < 1e-5
+        assert_grads_close(rec["grad.netD"], sub(z, f"critic{k}.grad.netD"), 1e-3, f"critic{k} grad D")
+        assert_params_close(st.pD, sub(z, f"critic{k}.after.netD"), 10 * lr, f"D after critic {k}")
+    st.losses.init_loss()
+    for k in range(2):
+        rec = {}
+        fake = O.genb_iteration(st, z[f"x{k}"], z[f"y{k}"], rec=rec)
+        assert relerr(rec["errD"], z[f"it{k}.errD"]) < 1e-5
+        assert relerr(rec["errG"], z[f"it{k}.errG"]) < 1e-5
+        assert relerr(fake, z[f"it{k}.fake_y"]) < 1e-4
+        assert_grads_close(rec["dphase.grad.netD"], sub(z, f"it{k}.dphase.grad.netD"), 1e-3, f"it{k} grad D")
+        assert_grads_close(rec["gphase.grad.netG"], sub(z, f"it{k}.gphase.grad.netG"), 1e-3, f"it{k} grad G")
+        assert_params_close(st.pD, sub(z, f"it{k}.after.netD"), lr, f"D after it{k}")
+        assert_params_close(st.pG, sub(z, f"it{k}.after.netG"), lr, f"G after it{k}")
+    log = st.losses.loss(1)
+    assert list(log.keys()) == list(z["loss.keys"])
+    np.testing.assert_allclose([float(v) for v in log.values()], z["loss.values"], atol=1.5e-3)
+
+
+def test_genb_metric_scoring(golden_dir):
+    """metrics.py:19-27 scores only the first len(true) rows of a longer pred."""
+    z = load(golden_dir, "genb.npz")
+    t, p, m = z["metric.true"], z["metric.pred"], z["metric.mask"]
+    nme, nmae, rmse = O.metrics(t, p[: t.shape[0]], m)
+    np.testing.assert_allclose([nmae, rmse, nme], z["metric.out"], rtol=1e-9)
