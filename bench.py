@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full", action="store_true", help="also time band/adjust/scores inside the step")
+    ap.add_argument("--share-gpass", action="store_true",
+                    help="NOT the headline schedule: one generator forward/backward per iteration instead of the "
+                         "reference's two identical forwards (see TIMEBANDTrainer.share_gpass)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +129,8 @@ def main():
     cfg = CONFIGS[args.config]
     ds, trainset, trainer = build(cfg, device)
     B = cfg["B"]
+    if args.share_gpass:
+        trainer.share_gpass = True
     from timeband_amd import _lib, ops
     lib = _lib.load()
     nbatches = len(trainset) // (B * world)
@@ -186,7 +191,8 @@ def main():
             "config": {"workload": f"{args.config}: LSTM-GAN G+D iteration (critic=1 + D phase + G phase), "
                                    f"V={cfg['V']} E={cfg['V'] + cfg['NT']} window={cfg['To']} hidden={cfg['H']} "
                                    f"layers={cfg['L']} batch={B}/GPU", "global_batch": B * world,
-                       "parallelism": f"dp{world}", "full_iteration": bool(args.full)},
+                       "parallelism": f"dp{world}", "full_iteration": bool(args.full),
+                       **({"shared_generator_pass": True} if args.share_gpass else {})},
             "roofline": {"bound": "hbm", "kernel": f"{dom}_kernel (persistent recurrent, all LSTM layers)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

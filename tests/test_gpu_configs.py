@@ -232,19 +232,50 @@ def test_full_size_gradients_add_over_the_batch(dev, cfg2_nets):
 
 
 def test_overlapped_iteration_equals_single_stream(dev):
-    """TIMEBANDTrainer.iteration with the generator forwards on side streams (default) and on one stream
-    (TB_OVERLAP=0) leave bit-identical parameters after two iterations."""
+    """TIMEBANDTrainer.iteration with the generator work on side streams (default, and each part of it
+    alone: TB_OVERLAP bit mask) and on one stream (TB_OVERLAP=0) leave bit-identical parameters after
+    two iterations."""
     import bench
     cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
     results = []
-    for overlap in (True, False):
+    for mask in (5, 0, 1, 2, 4, 7):
         np.random.seed(3)
         ds, trainset, trainer = bench.build(cfg, dev)
-        trainer.overlap = overlap
+        trainer.overlap, trainer.overlap_mask = mask != 0, mask
         for i in range(2):
             b = trainset.gather(i * cfg["B"], cfg["B"])
             trainer.iteration(b["encoded"], b["decoded"], training=True)
         torch.cuda.synchronize()
         results.append([p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()])
-    for a, b in zip(*results):
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
+
+
+def test_shared_generator_pass_matches_two_passes(dev):
+    """TB_SHARE_GPASS: one generator forward and one backward with the summed upstream gradient against
+    the reference's schedule (two identical forwards, two backwards): same fake_y bit for bit, parameters
+    equal up to the rounding of that sum (Adam turns it into at most a fraction of one step)."""
+    import bench
+    cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
+    res = []
+    for share in (False, True):
+        np.random.seed(3)
+        ds, trainset, trainer = bench.build(cfg, dev)
+        trainer.share_gpass = share
+        b = trainset.gather(0, cfg["B"])
+        fake = trainer.iteration(b["encoded"], b["decoded"], training=True)
+        torch.cuda.synchronize()
+        res.append((fake.clone(), [p.detach().clone() for p in trainer.models.netG.parameters()],
+                    [p.detach().clone() for p in trainer.models.netD.parameters()], trainer.lr))
+    (fa, ga, da, lr), (fb, gb, db, _) = res
+    assert torch.equal(fa, fb)
+    for a, b in zip(da, db):
         assert torch.equal(a, b)
+    nbad = ntot = 0
+    for a, b in zip(ga, gb):
+        d = (a - b).abs()
+        assert float(d.max()) <= 2.1 * lr
+        nbad += int((d > 0.05 * lr).sum())
+        ntot += d.numel()
+    assert nbad / ntot < 2e-3, (nbad, ntot)

@@ -36,10 +36,20 @@ class TIMEBANDTrainer:
         self.forecast_len = self.dataset.forecast_len
         self.post = BandAdjust(dataset, "trainer", self.band_width, self.missing_gamma, self.anomaly_gamma)
         self.optimD = self.optimG = None
-        # The two generator forwards of an iteration depend only on G's parameters, which do not change
-        # until the very end: they run on side streams, under the critic step and under the D-phase
-        # backward (latency-bound persistent kernels leave most of the chip idle).  TB_OVERLAP=0: one stream.
-        self.overlap = os.environ.get("TB_OVERLAP", "1") != "0"
+        # The D-phase generator forward depends only on G's parameters, which do not change until the very
+        # end of the iteration: it runs on a side stream under the critic step; the graph is cut at fake_y
+        # so the generator's backward passes run on side streams too (latency-bound persistent kernels
+        # leave most of the chip idle).  TB_OVERLAP is a bit mask (see iteration()); 0 = one stream.
+        # Default 5: putting the G-phase forward under the D-phase backward as well (bit 2) measured
+        # 1.4 % slower -- the two stretch each other by more than the forward takes.
+        ov = os.environ.get("TB_OVERLAP", "5")
+        self.overlap_mask = int(ov) if ov.isdigit() else 5
+        self.overlap = self.overlap_mask != 0
+        # TB_SHARE_GPASS=1 (off by default; not the reference's schedule): G's parameters are the same in
+        # the D phase and the G phase, so netG(true_x) is the same tensor both times and backward is linear
+        # in the upstream gradient -- one generator forward and ONE backward with the summed gradient give
+        # the same update up to fp32 rounding of that sum.
+        self.share_gpass = os.environ.get("TB_SHARE_GPASS", "0") == "1"
         self._side = None
 
     def set_config(self, config: dict = None) -> None:
@@ -127,6 +137,13 @@ class TIMEBANDTrainer:
         draws from dataset.get_random()).  Returns the G-phase fake_y."""
         netD, netG = self.models.netD, self.models.netG
         overlap = self.overlap and training and true_x.is_cuda
+        # which parts overlap (TB_OVERLAP bit mask, default 5): 1 = D-phase generator forward under the
+        # critic step, 2 = G-phase generator forward under the D-phase backward, 4 = graph cut at fake_y
+        # (generator backward on a side stream)
+        ov1, ov2, ov4 = ((overlap and bool(self.overlap_mask & b)) for b in (1, 2, 4))
+        share = self.share_gpass and training
+        if share:
+            ov2 = False
         if overlap:
             main = torch.cuda.current_stream(true_x.device)
             if self._side is None:
@@ -135,6 +152,7 @@ class TIMEBANDTrainer:
                 # created on the main one: intended here
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             s1, s2 = self._side
+        if ov1:
             s1.wait_stream(main)
             with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step
                 fake_y = netG(true_x)
@@ -154,22 +172,25 @@ class TIMEBANDTrainer:
         self.optimG.zero_grad()
         # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
         with torch.set_grad_enabled(training):
-            if overlap:
+            if ov1:
                 main.wait_stream(s1)
-                # cut the graph at fake_y: D's backward runs on this stream, G's (below) on the side one
-                fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
             else:
                 fake_y = netG(true_x)
+            if ov4 or share:
+                # cut the graph at fake_y: D's backward runs on this stream, G's (below) on the side one
+                fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
             Dy, DGx = netD.pair(true_y, fake_y)
             errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx)
-        if overlap:
+        if ov2:
             s2.wait_stream(main)
             with torch.cuda.stream(s2):          # G-phase generator forward, under the D-phase backward
                 fake_y2 = netG(true_x)
             fake_y2.record_stream(main)
         if training:
             errD.backward()
-            if overlap:      # the generator's share of errD.backward(), under the G-phase discriminator pass
+            if share:
+                dfake_dphase = fake_y.grad
+            elif ov4:        # the generator's share of errD.backward(), under the G-phase discriminator pass
                 s1.wait_stream(main)
                 with torch.cuda.stream(s1):
                     fake_g.backward(fake_y.grad)
@@ -183,20 +204,32 @@ class TIMEBANDTrainer:
             p.requires_grad_(False)
         try:
             with torch.set_grad_enabled(training):
-                if overlap:
+                if share:
+                    fake_y = fake_g.detach().requires_grad_()
+                elif ov2:
                     main.wait_stream(s2)
-                    fake_g, fake_y = fake_y2, fake_y2.detach().requires_grad_()
+                    fake_y = fake_y2
                 else:
                     fake_y = netG(true_x)
+                if ov4 and not share:
+                    fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
                 DGx = netD(fake_y)
                 errG = self.losses.gen_loss(true_y, fake_y, DGx)
             if training:
                 errG.backward()
-                if overlap:  # G-phase generator backward after the D-phase one (both add into G's gradients)
+                if share:
+                    fake_g.backward(dfake_dphase + fake_y.grad)
+                    if overlap:
+                        main.wait_stream(s1)
+                        main.wait_stream(s2)
+                elif ov4:    # G-phase generator backward after the D-phase one (both add into G's gradients)
                     s2.wait_stream(main)
                     s2.wait_stream(s1)
                     with torch.cuda.stream(s2):
                         fake_g.backward(fake_y.grad)
+                    main.wait_stream(s2)
+                elif overlap:
+                    main.wait_stream(s1)
                     main.wait_stream(s2)
         finally:
             for p in dparams:

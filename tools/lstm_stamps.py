@@ -28,6 +28,15 @@ for (B, T, In, H) in cases:
     x = (torch.rand(B, T, In, generator=g) * 2 - 1).to(dev).requires_grad_()
     dy = (torch.rand(B, T, H, generator=g) * 2 - 1).to(dev)
     for it in range(3):
+        if "--corun" in sys.argv:      # the same forward on two streams at once
+            x2 = x.detach().clone()
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            torch.cuda.synchronize()
+            for s_, xx in zip(streams, (x, x2)):
+                with torch.cuda.stream(s_), torch.no_grad():
+                    y = ops.lstm_layer(xx, w_ih, w_hh, b_ih, b_hh)
+            torch.cuda.synchronize()
+            continue
         if "--infer" in sys.argv:
             with torch.no_grad():
                 y = ops.lstm_layer(x, w_ih, w_hh, b_ih, b_hh)
