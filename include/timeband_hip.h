@@ -42,6 +42,9 @@ int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host, double* 
  *           cstash may be NULL.
  * backward: dy (B,T,H) -> dx (B,T,in) [nullable], dw_ih, dw_hh, db_ih, db_hh [each nullable];
  *           `gates` is consumed (overwritten with the pre-activation gradients).
+ *           accumulate != 0: the four parameter gradients are ADDED to what the buffers hold (what
+ *           autograd's `.grad +=` does, trainer.py:179-180,193); dx is always overwritten.  The same flag
+ *           on tb_linear_bwd (dW, db) and tb_head_bwd (dw, db).
  * H must be one of 16,32,64,128,256,512 (tb_lstm_supported).  `err` is a device int[4]: err[0]
  * becomes non-zero if an inter-workgroup wait timed out (results are then invalid). */
 int tb_lstm_supported(int H);
@@ -51,8 +54,8 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
                 void* ws, size_t ws_bytes, int* err, void* stream);
 int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
                 float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
-                float* db_hh, int B, int T, int in_dim, int H, void* ws, size_t ws_bytes, int* err,
-                void* stream);
+                float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
+                int* err, void* stream);
 
 /* ---- Linear (+Tanh / +Sigmoid) -----------------------------------------------------------------
  * y[M,N] = act(x[M,K].W[N,K]^T + b[N]); act 0 none, 1 tanh, 2 sigmoid.
@@ -62,7 +65,7 @@ int tb_linear_act_fwd(const float* x, const float* W, const float* b, float* y, 
                       void* stream);
 size_t tb_linear_workspace_bytes(int M, int K, int N);
 int tb_linear_bwd(const float* dz, const float* x, const float* W, float* dx, float* dW, float* db, int M, int K,
-                  int N, void* ws, size_t ws_bytes, void* stream);
+                  int N, int accumulate, void* ws, size_t ws_bytes, void* stream);
 int tb_act_bwd(const float* dy, const float* y, float* dz, long n, int act, void* stream);
 size_t tb_colsum_workspace_bytes(int cols);
 int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream);
@@ -76,7 +79,7 @@ int tb_head_supported(int K);
 size_t tb_head_workspace_bytes(long M, int K);
 int tb_head_fwd(const float* x, const float* w, const float* b, float* out, long M, int K, int act, void* stream);
 int tb_head_bwd(const float* dy, const float* out, const float* x, const float* w, float* dx, float* dw, float* db,
-                long M, int K, int act, void* ws, size_t ws_bytes, void* stream);
+                long M, int K, int act, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- losses (source/loss.py) ---------------------------------------------------------------------
  * tb_loss_sums: one pass over whichever inputs are non-NULL into a device double[8]:

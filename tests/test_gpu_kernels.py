@@ -392,3 +392,43 @@ def test_denormalize_bit_exact(dev):
     dmax = dmin + rng.uniform(0.5, 9, 4)
     got = ops.denormalize(T(x, dev), T(dmin, dev, torch.float64), T(dmax, dev, torch.float64))
     assert np.array_equal(got.cpu().numpy(), O.denormalize(x, dmin, dmax))
+
+
+@pytest.mark.parametrize("B,T", [(3, 5), (40, 24)])
+def test_gradients_accumulate_into_flat_slots(dev, B, T):
+    """With optim.flatten() the backward kernels add parameter gradients straight into the flat gradient
+    buffer (`accumulate` of tb_lstm_bwd / tb_linear_bwd / tb_head_bwd): two backward passes must leave
+    the same sums as autograd's own accumulation on an un-flattened copy (small B*T: no split-K)."""
+    import copy
+    from timeband_amd import ops
+    from timeband_amd.optim import flatten
+    torch.manual_seed(5)
+    In, H, N = 12, 64, 7
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lstm = torch.nn.LSTM(In, H, 1, batch_first=True)
+            self.lin = torch.nn.Linear(H, N)
+            self.head = torch.nn.Linear(H, 1)
+
+        def forward(self, x):
+            r = ops.lstm_stack(x, self.lstm)
+            a = ops.linear_act(r.reshape(-1, H), self.lin.weight, self.lin.bias, ops.ACT_TANH)
+            b = ops.linear_act(r.reshape(-1, H), self.head.weight, self.head.bias, ops.ACT_SIGMOID)
+            return a.sum() * 0.5 + (b * b).sum()
+
+    plain = Net().to(dev)
+    flat = copy.deepcopy(plain)
+    fp = flatten(flat)
+    xs = [torch.rand(B, T, In, device=dev) * 2 - 1 for _ in range(2)]
+    for x in xs:
+        plain(x).backward()
+        flat(x).backward()
+    for (k, p), q in zip(plain.named_parameters(), flat.parameters()):
+        assert q.grad.data_ptr() == q._tb_grad_slot.data_ptr()
+        # not bit-equal: the flat slices sit at other alignments than the separate tensors, which selects
+        # other (equally valid) kernel variants and summation orders
+        assert rel(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-5, k
+    fp.check()
+    assert float(fp.grad.abs().sum()) > 0

@@ -31,17 +31,17 @@ SIGNATURES = {
     "tb_lstm_supported": (I, [I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
-    "tb_lstm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
     "tb_linear_act_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "tb_linear_workspace_bytes": (Z, [I, I, I]),
-    "tb_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, P, Z, P]),
+    "tb_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, Z, P]),
     "tb_act_bwd": (I, [P, P, P, L, I, P]),
     "tb_colsum_workspace_bytes": (Z, [I]),
     "tb_colsum": (I, [P, L, I, P, P, Z, P]),
     "tb_head_supported": (I, [I]),
     "tb_head_workspace_bytes": (Z, [L, I]),
     "tb_head_fwd": (I, [P, P, P, P, L, I, I, P]),
-    "tb_head_bwd": (I, [P, P, P, P, P, P, P, L, I, I, P, Z, P]),
+    "tb_head_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, P, Z, P]),
     "tb_loss_workspace_bytes": (Z, []),
     "tb_loss_sums": (I, [P, L, P, L, P, P, L, P, P, Z, P]),
     "tb_loss_finish": (I, [P, I, D, D, D, D, F, F, F, P, P, P]),

@@ -8,7 +8,7 @@
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
-                   float* ws, size_t ws_bytes, hipStream_t stream);
+                   float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
 
 namespace {
 thread_local char g_err[512] = "";
@@ -120,7 +120,7 @@ int tb_prof_read(int kernel_id, int* count, double* total_ms, double* algo_bytes
 int tb_linear_act_fwd(const float* x, const float* W, const float* b, float* y, int M, int K, int N, int act,
                       void* stream) {
   if (!x || !W || !y) return tb_set_error(TB_ERR_ARG, "linear_act_fwd: null pointer");
-  return tb_gemm_launch(x, K, 0, W, K, 0, y, N, b, M, N, K, act, 0, 1, nullptr, 0, static_cast<hipStream_t>(stream));
+  return tb_gemm_launch(x, K, 0, W, K, 0, y, N, b, M, N, K, act, 0, 1, nullptr, 0, static_cast<hipStream_t>(stream), 0);
 }
 
 size_t tb_colsum_workspace_bytes(int cols);
@@ -131,28 +131,28 @@ size_t tb_linear_workspace_bytes(int M, int K, int N) {
 
 // dz = dy * act'(y) must already have been applied by the caller when act != 0 (tb_act_bwd).
 // dx[M,K] = dz.W ; dW[N,K] = dz^T.x ; db[N] = colsum(dz).  Any of dx/dW/db may be null.
-int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream);
+int tb_colsum_acc(const float* a, long rows, int cols, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 int tb_linear_bwd(const float* dz, const float* x, const float* W, float* dx, float* dW, float* db, int M, int K,
-                  int N, void* ws, size_t ws_bytes, void* stream) {
+                  int N, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!dz) return tb_set_error(TB_ERR_ARG, "linear_bwd: null pointer");
   if (ws_bytes < tb_linear_workspace_bytes(M, K, N)) return tb_set_error(TB_ERR_WORKSPACE, "linear_bwd: workspace too small");
   int rc;
   if (dx) {
     if (!W) return tb_set_error(TB_ERR_ARG, "linear_bwd: W is null");
-    rc = tb_gemm_launch(dz, N, 0, W, K, 1, dx, K, nullptr, M, K, N, 0, 0, 1, nullptr, 0, s);
+    rc = tb_gemm_launch(dz, N, 0, W, K, 1, dx, K, nullptr, M, K, N, 0, 0, 1, nullptr, 0, s, 0);
     if (rc) return rc;
   }
   const size_t cs = tb_align_up(tb_colsum_workspace_bytes(N), 256);
   if (dW) {
     if (!x) return tb_set_error(TB_ERR_ARG, "linear_bwd: x is null");
     rc = tb_gemm_launch(dz, N, 1, x, K, 1, dW, K, nullptr, N, K, M, 0, 0, 1,
-                        reinterpret_cast<float*>(static_cast<char*>(ws) + cs), ws_bytes - cs, s);
+                        reinterpret_cast<float*>(static_cast<char*>(ws) + cs), ws_bytes - cs, s, accumulate);
     if (rc) return rc;
   }
   if (db) {
-    rc = tb_colsum(dz, M, N, db, ws, cs, s);
+    rc = tb_colsum_acc(dz, M, N, db, accumulate, ws, cs, s);
     if (rc) return rc;
   }
   return TB_OK;

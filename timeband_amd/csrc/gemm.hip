@@ -285,7 +285,7 @@ __global__ void splitk_group_kernel(float* __restrict__ slab, int splits, long t
 
 // C[m][n] = act(sum over z = 0, zstep, 2*zstep, ... < splits of slab[z][m][n] + bias[n])
 __global__ void splitk_final_kernel(const float* __restrict__ slab, int splits, int zstep, int M, int N, float* C,
-                                    long ldc, const float* bias, int act) {
+                                    long ldc, const float* bias, int act, int accumulate) {
   const long total = (long)M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -294,7 +294,17 @@ __global__ void splitk_final_kernel(const float* __restrict__ slab, int splits, 
     if (bias) s += bias[n];
     if (act == 1) s = tanhf(s);
     else if (act == 2) s = tb_sigmoid(s);
+    if (accumulate) s += C[(long)m * ldc + n];
     C[(long)m * ldc + n] = s;
+  }
+}
+
+// C[m][n] += tmp[m][n]: the accumulate form of a product that needed no k split
+__global__ void accumulate_kernel(const float* __restrict__ tmp, int M, int N, float* C, long ldc) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    C[(long)m * ldc + n] += tmp[i];
   }
 }
 
@@ -322,10 +332,14 @@ size_t tb_gemm_ws_bytes() { return (size_t)3 * tb_num_cus() * 128 * 128 * sizeof
 
 // Host-side launcher shared by the C-ABI entry points (capi.hip, lstm.hip).
 // transA: 0 -> A is [M][K]; 1 -> A is [K][M].   transB: 0 -> B is [N][K]; 1 -> B is [K][N].
+// accumulate: C += the product (weight gradients added straight into a gradient buffer); needs a workspace
+// of at least M x N floats.
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
-                   float* ws, size_t ws_bytes, hipStream_t stream) {
+                   float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
   if (M <= 0 || N <= 0) return TB_OK;
+  if (accumulate && (!ws || ws_bytes < (size_t)M * N * sizeof(float)))
+    return tb_set_error(TB_ERR_WORKSPACE, "gemm: accumulate needs a workspace of M x N floats");
   if (K <= 0) return tb_set_error(TB_ERR_ARG, "gemm: K must be positive");
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias;
@@ -364,6 +378,12 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
   a.kchunk = kchunk;
   a.splits = splits;
   a.slab = ws;
+  float* const Cout = C;
+  const long ldout = ldc;
+  if (accumulate && splits == 1) {   // product into the workspace, added to C below
+    a.C = ws;
+    a.ldc = N;
+  }
   // persistent grid: as many blocks as stay resident (2 per CU by registers, 3 for the narrow tiles)
   long items = tiles * splits;
   const long resident = (long)cus * (cfg == 0 ? 3 : 2);
@@ -387,8 +407,13 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_final_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, zstep, M, N, C, ldc, bias,
-                       act);
+                       act, accumulate);
     TB_LAUNCH_CHECK("splitk_final_kernel");
+  } else if (accumulate) {
+    int blocks = (int)(((long)M * N + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(256), 0, stream, ws, M, N, Cout, ldout);
+    TB_LAUNCH_CHECK("accumulate_kernel");
   }
   tb_prof_end(TB_K_GEMM, stream);
   return TB_OK;

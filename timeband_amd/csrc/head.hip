@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 // dw[k] / db = sum over the block partials, in a fixed order: one block per 4 columns, 64 threads per
 // column each summing every 64th partial, then one thread per column adds the 64 sums in order.
 __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int nparts, int K, float* dw,
-                                                          float* db) {
+                                                          float* db, int accumulate) {
   __shared__ float sm[64][4];
   const int c = threadIdx.x & 3, g = threadIdx.x >> 2;
   const int k = blockIdx.x * 4 + c;
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     float t = 0.f;
     for (int i = 0; i < 64; ++i) t += sm[i][c];
     if (k < K) {
-      if (dw) dw[k] = t;
+      if (dw) dw[k] = accumulate ? dw[k] + t : t;
     } else if (db) {
-      db[0] = t;
+      db[0] = accumulate ? db[0] + t : t;
     }
   }
 }
@@ -168,7 +168,7 @@ int tb_head_fwd(const float* x, const float* w, const float* b, float* out, long
 
 // dy = gradient wrt out; out = forward result (read only when act != 0).  Any of dx / dw / db may be null.
 int tb_head_bwd(const float* dy, const float* out, const float* x, const float* w, float* dx, float* dw, float* db,
-                long M, int K, int act, void* ws, size_t ws_bytes, void* stream) {
+                long M, int K, int act, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (M <= 0) return TB_OK;
   if (!dy || (act && !out) || (dw && !x) || (dx && !w) || !ws) return tb_set_error(TB_ERR_ARG, "head_bwd: null pointer");
@@ -184,7 +184,7 @@ int tb_head_bwd(const float* dy, const float* out, const float* x, const float* 
   else hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, dy, out, x, w, dx, part, M, K, act, need_dw);
   TB_LAUNCH_CHECK("head_bwd_kernel");
   if (dw || db) {
-    hipLaunchKernelGGL(head_reduce_kernel, dim3((K + 4) / 4), dim3(256), 0, s, part, grid, K, dw, db);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((K + 4) / 4), dim3(256), 0, s, part, grid, K, dw, db, accumulate);
     TB_LAUNCH_CHECK("head_reduce_kernel");
   }
   return TB_OK;

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 }
 
 __global__ __launch_bounds__(64) void colsum_final_kernel(const double* __restrict__ part, int nparts, int cols,
-                                                          float* out) {
+                                                          float* out, int accumulate) {
   // one wave per column: lanes stride the partials, then a fixed-order tree over the lanes
   const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const double* __restri
     if (lane < w) sh[lane] += sh[lane + w];
     __syncthreads();
   }
-  if (lane == 0) out[c] = (float)sh[0];
+  if (lane == 0) out[c] = accumulate ? out[c] + (float)sh[0] : (float)sh[0];
 }
 
 // torch.optim.Adam (no weight decay / amsgrad); operation order follows torch's single-tensor path
@@ -288,7 +288,14 @@ constexpr int kColsumMaxParts = 1024;
 
 size_t tb_colsum_workspace_bytes(int cols) { return (size_t)kColsumMaxParts * cols * sizeof(double) + 256; }
 
+int tb_colsum_acc(const float* a, long rows, int cols, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t ws_bytes, void* stream) {
+  return tb_colsum_acc(a, rows, cols, out, 0, ws, ws_bytes, stream);
+}
+
+// accumulate: out[c] += the column sum (internal form used by tb_linear_bwd)
+int tb_colsum_acc(const float* a, long rows, int cols, float* out, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (cols <= 0) return TB_OK;
   if (!a || !out || !ws) return tb_set_error(TB_ERR_ARG, "colsum: null pointer");
@@ -305,7 +312,7 @@ int tb_colsum(const float* a, long rows, int cols, float* out, void* ws, size_t 
   double* part = static_cast<double*>(ws);
   hipLaunchKernelGGL(colsum_kernel, dim3((int)parts, ycount), dim3(256), 0, s, a, rows, cols, cw, part);
   TB_LAUNCH_CHECK("colsum_kernel");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(64), 0, s, part, (int)parts, cols, out);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cols), dim3(64), 0, s, part, (int)parts, cols, out, accumulate);
   TB_LAUNCH_CHECK("colsum_final_kernel");
   return TB_OK;
 }

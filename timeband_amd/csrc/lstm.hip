@@ -41,7 +41,7 @@
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
-                   float* ws, size_t ws_bytes, hipStream_t stream);
+                   float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
 
 #ifdef TB_STAMPS
 // Diagnostic build only (tools/lstm_stamps.py): per-segment cycle sums of one workgroup's step loop.
@@ -898,13 +898,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   }
 }
 
-__global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* db_ih, float* db_hh) {
+__global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* db_ih, float* db_hh,
+                                 int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
   for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
-  if (db_ih) db_ih[i] = s;
-  if (db_hh) db_hh[i] = s;
+  if (db_ih) db_ih[i] = accumulate ? db_ih[i] + s : s;
+  if (db_hh) db_hh[i] = accumulate ? db_hh[i] + s : s;
 }
 
 __global__ void bias_sum_kernel(const float* b1, const float* b2, float* out, int n) {
@@ -1097,7 +1098,7 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     bias = c.bsum;
   }
   int rc = tb_gemm_launch(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, bias, B * T, 4 * H, in_dim, 0, 0, 1,
-                          nullptr, 0, s);
+                          nullptr, 0, s, 0);
   if (rc) return rc;
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   // algorithmic bytes of one layer forward: read x, write h, write the 5h stash
@@ -1124,7 +1125,7 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
 
 int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
                 float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
-                float* db_hh, int B, int T, int in_dim, int H, void* ws, size_t ws_bytes, int* err,
+                float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, int* err,
                 void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
@@ -1161,23 +1162,23 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   tb_prof_end(TB_K_LSTM_BWD, s);
   if (db_ih || db_hh) {
     hipLaunchKernelGGL(db_reduce_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, c.dbpart, ncl_total, 4 * H,
-                       db_ih, db_hh);
+                       db_ih, db_hh, accumulate);
     TB_LAUNCH_CHECK("db_reduce_kernel");
   }
   const int M = B * T;
   if (dx) {   // dx = dG . W_ih            [M,4H].[4H,in]
     rc = tb_gemm_launch(gates, 4L * H, 0, w_ih, in_dim, 1, dx, in_dim, nullptr, M, in_dim, 4 * H, 0, 0, 1,
-                        c.gemm_ws, c.gemm_ws_bytes, s);
+                        c.gemm_ws, c.gemm_ws_bytes, s, 0);
     if (rc) return rc;
   }
   if (dw_ih) {  // dW_ih = dG^T . x        [4H,M].[M,in]
     rc = tb_gemm_launch(gates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, nullptr, 4 * H, in_dim, M, 0, 0, 1,
-                        c.gemm_ws, c.gemm_ws_bytes, s);
+                        c.gemm_ws, c.gemm_ws_bytes, s, accumulate);
     if (rc) return rc;
   }
   if (dw_hh) {  // dW_hh = dG^T . h_prev,  h_prev[b,t] = y[b,t-1], 0 at t = 0
     rc = tb_gemm_launch(gates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, c.gemm_ws,
-                        c.gemm_ws_bytes, s);
+                        c.gemm_ws_bytes, s, accumulate);
     if (rc) return rc;
   }
   return TB_OK;

@@ -77,12 +77,31 @@ def check_errors(device=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# Parameter gradients straight into a gradient buffer.  optim.FlatParams gives every parameter a
+# `_tb_grad_slot` (its slice of the network's flat gradient buffer, which is also its .grad); when
+# all the parameters of an op have one, the backward kernels ADD their result into the slots
+# (`accumulate` of the C-ABI) and autograd gets None for them -- the same sums as autograd's own
+# `grad += new` without a temporary and an add kernel per parameter and backward pass.
+# ----------------------------------------------------------------------------------------------
+def _slots(need, *params):
+    """Slots of the parameters that need a gradient, or None if any of those has none."""
+    out = []
+    for n, p in zip(need, params):
+        s = getattr(p, "_tb_grad_slot", None) if (n and p is not None) else None
+        if n and p is not None and (s is None or s.shape != p.shape or not s.is_contiguous()):
+            return None
+        out.append(s)
+    return out if any(s is not None for s in out) else None
+
+
+# ----------------------------------------------------------------------------------------------
 # LSTM layer
 # ----------------------------------------------------------------------------------------------
 class _LSTMLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train):
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh)
+        ctx.params = (w_ih, w_hh, b_ih, b_hh)
         x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
         B, T, In = x.shape
         H = w_hh.shape[1]
@@ -119,15 +138,21 @@ class _LSTMLayerFn(torch.autograd.Function):
         lib = _lib.load()
         need = ctx.needs_input_grad
         dx = torch.empty_like(x) if need[0] else None
-        dw_ih = torch.empty_like(w_ih) if need[1] else None
-        dw_hh = torch.empty_like(w_hh) if need[2] else None
-        db_ih = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[3] else None
-        db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[4] else None
+        slots = _slots(need[1:5], *ctx.params)
+        if slots is not None:
+            dw_ih, dw_hh, db_ih, db_hh = slots
+        else:
+            dw_ih = torch.empty_like(w_ih) if need[1] else None
+            dw_hh = torch.empty_like(w_hh) if need[2] else None
+            db_ih = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[3] else None
+            db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[4] else None
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 1)
         ws = rt.workspace(nws)
         _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
-                  _ptr(dx), _ptr(dw_ih), _ptr(dw_hh), _ptr(db_ih), _ptr(db_hh), B, T, In, H, _ptr(ws), ws.numel(),
-                  _ptr(rt.err), _stream())
+                  _ptr(dx), _ptr(dw_ih), _ptr(dw_hh), _ptr(db_ih), _ptr(db_hh), B, T, In, H,
+                  1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+        if slots is not None:
+            return dx, None, None, None, None, None
         return dx, dw_ih, dw_hh, db_ih, db_hh, None
 
 
@@ -153,6 +178,7 @@ class _LinearActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act):
         _need_cuda(x, W, b)
+        ctx.params = (W, b)
         x, W = _f32c(x), _f32c(W)
         b = _f32c(b) if b is not None else None
         M, K = x.shape
@@ -182,11 +208,17 @@ class _LinearActFn(torch.autograd.Function):
             dz = dy
         need = ctx.needs_input_grad
         dx = torch.empty_like(x) if need[0] else None
-        dW = torch.empty_like(W) if need[1] else None
-        db = torch.empty(N, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
+        slots = _slots((need[1], need[2] and ctx.has_b), *ctx.params)
+        if slots is not None:
+            dW, db = slots
+        else:
+            dW = torch.empty_like(W) if need[1] else None
+            db = torch.empty(N, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
         ws = rt.workspace(lib.tb_linear_workspace_bytes(M, K, N))
-        _lib.call("tb_linear_bwd", _ptr(dz), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, N, _ptr(ws),
-                  ws.numel(), _stream())
+        _lib.call("tb_linear_bwd", _ptr(dz), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, N,
+                  1 if slots is not None else 0, _ptr(ws), ws.numel(), _stream())
+        if slots is not None:
+            return dx, None, None, None
         return dx, dW, db, None
 
 
@@ -196,6 +228,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, act):
         _need_cuda(x, W, b)
+        ctx.params = (W, b)
         x, W = _f32c(x), _f32c(W)
         b = _f32c(b) if b is not None else None
         M, K = x.shape
@@ -215,11 +248,17 @@ class _HeadFn(torch.autograd.Function):
         rt = Runtime.get(dev)
         need = ctx.needs_input_grad
         dx = torch.empty_like(x) if need[0] else None
-        dW = torch.empty_like(W) if need[1] else None
-        db = torch.empty(1, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
+        slots = _slots((need[1], need[2] and ctx.has_b), *ctx.params)
+        if slots is not None:
+            dW, db = slots
+        else:
+            dW = torch.empty_like(W) if need[1] else None
+            db = torch.empty(1, dtype=torch.float32, device=dev) if (need[2] and ctx.has_b) else None
         ws = rt.workspace(_lib.load().tb_head_workspace_bytes(M, K))
         _lib.call("tb_head_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, ctx.act,
-                  _ptr(ws), ws.numel(), _stream())
+                  1 if slots is not None else 0, _ptr(ws), ws.numel(), _stream())
+        if slots is not None:
+            return dx, None, None, None
         return dx, dW, db, None
 
 

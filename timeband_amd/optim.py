@@ -28,6 +28,7 @@ class FlatParams:
             self.data[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.data[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
+            p._tb_grad_slot = p.grad        # the backward kernels add into it directly (ops._slots)
             off += k
 
     def check(self):
@@ -39,6 +40,7 @@ class FlatParams:
                 raise RuntimeError("a parameter no longer aliases the flat buffer (module.to()/load after flatten?)")
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + k].view(p.shape)
+                p._tb_grad_slot = p.grad
             off += k
 
 

@@ -37,10 +37,12 @@ for r in seg:
     agg[key][1] += e - s
     busy += e - s
     if "--agg" not in sys.argv:
-        print(f"{(s - t0) / 1e3:9.1f}us +{(e - s) / 1e3:8.1f}us gap{(s - prev_end) / 1e3:7.1f} {key[0]} grid={key[1]},{key[2]},{key[3]}")
+        print(f"{(s - t0) / 1e3:9.1f}us +{(e - s) / 1e3:8.1f}us gap{(s - prev_end) / 1e3:7.1f} q{r.get('Queue_Id', '?')} {key[0]} grid={key[1]},{key[2]},{key[3]}")
     prev_end = max(prev_end, e)
 span = int(seg[-1]["End_Timestamp"]) - t0
 print(f"step span {span / 1e6:.3f} ms, kernel busy {busy / 1e6:.3f} ms, {len(seg)} dispatches")
+small = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 12000]
+print(f"dispatches under 12 us: {len(small)}, {sum(small) / 1e6:.3f} ms in total")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     print(f"{v[1] / 1e3:9.1f}us n={v[0]:3d} avg={v[1] / v[0] / 1e3:8.1f}us {k[0]} grid={k[1]},{k[2]},{k[3]}")
 # concurrency of the last step: union of busy intervals vs their sum, and per-queue busy time
