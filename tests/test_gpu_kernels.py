@@ -432,3 +432,34 @@ def test_gradients_accumulate_into_flat_slots(dev, B, T):
         assert rel(q.grad.cpu().numpy(), p.grad.cpu().numpy()) < 2e-5, k
     fp.check()
     assert float(fp.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("variant", ["trainer", "cleaner", "predictor"])
+def test_adjust_scan_long_series_vs_oracle(dev, variant):
+    """tb_adjust_scan on a series long enough for its parallel (chunked) form: runs of missing rows that
+    cross chunk borders, a column that is missing throughout (its chain goes back to the seed), a column
+    with no missing row; against the oracle's sequential scan.  Then the same with one NaN among the
+    predictions: the library falls back to the literal sequential order, and the NaN travels down its
+    column exactly as in the reference's arithmetic."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(11)
+    n, V = 700, 70
+    preds = rng.normal(size=(n, V)) * 3
+    sd = np.abs(rng.normal(size=(n, V))) + 0.1
+    lower, upper = preds - sd, preds + sd
+    output = rng.normal(size=(n + 1, V)) * 4
+    masks = (rng.random((n, V)) < 0.3).astype(np.int32)
+    masks[:, 3] = 1
+    masks[:, 5] = 0
+    masks[40:330, 7] = 1          # one run across four chunk borders
+    f64 = lambda a: T(a, dev, torch.float64)
+    for poison in (False, True):
+        if poison:
+            preds = preds.copy()
+            preds[350, 9] = np.nan
+        want = O.adjust(variant, output.copy(), preds, masks, lower, upper, 0.2, 0.3)
+        got = ops.adjust_scan(variant, f64(output[0]), f64(output[1:]), f64(preds), T(masks, dev, torch.int32),
+                              f64(lower), f64(upper), 0.2, 0.3).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13, equal_nan=True)
+        if poison:
+            assert np.isnan(got[350:, 9]).all() and np.isfinite(got[:350, 9]).all()

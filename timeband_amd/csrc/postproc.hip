@@ -6,6 +6,7 @@
 // source/metric.py:30-73.  Post-processing is float64 like the reference's numpy code; every
 // multiply-add that numpy performs as two rounded operations is kept as two (no fma contraction).
 #include "common.h"
+#include <atomic>
 
 #pragma clang fp contract(off)
 
@@ -121,9 +122,83 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __re
   }
 }
 
-// std smear over the last Tf rows (trainer.py:280-282), then the band
-__global__ void band_finish_kernel(const double* __restrict__ med, double* __restrict__ sd, int R, int Tf, int V,
-                                   double width, double* __restrict__ lower, double* __restrict__ upper) {
+// The same for forecast_len <= 64, one THREAD per (row, variable): consecutive lanes are consecutive
+// variables of a row, so every gather load is a contiguous run of the wave (the wave-per-item kernel above
+// reads 4 bytes per cache line), all loads of an item are in flight together, and the <= Tf values are
+// sorted IN REGISTERS by a fully unrolled bitonic network (NP = Tf rounded up to a power of two; missing
+// horizons and NaNs become +inf and sort to the end, so the first n sorted entries are the valid ones).
+constexpr int BAND_T_MAX = 64;    // 128 values per thread no longer fit the register file
+
+template <int NP>
+__device__ __forceinline__ void bitonic_sort(float (&a)[NP]) {
+#pragma unroll
+  for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float lo = fminf(a[i], a[l]), hi = fmaxf(a[i], a[l]);
+          const bool up = (i & k) == 0;
+          a[i] = up ? lo : hi;
+          a[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V,
+                                                        const float* __restrict__ hist, int nhist,
+                                                        double* __restrict__ med, double* __restrict__ sd) {
+  const long item = (long)blockIdx.x * 256 + threadIdx.x;
+  const long nitems = (long)(B + Tf - 1) * V;
+  if (item >= nitems) return;
+  const int r = (int)(item / V), v = (int)(item % V);
+  float a[NP];
+  int n = 0;
+#pragma unroll
+  for (int f = 0; f < NP; ++f) {
+    const int w = r - f;
+    float x = __builtin_nanf("");
+    if (f < Tf) {
+      if (w >= 0 && w < B) x = pden[((long)w * Tf + f) * V + v];
+      else if (w < 0 && -w <= nhist) x = hist[((long)(Tf - 1 + w) * Tf + f) * V + v];
+    }
+    const bool ok = !isnan(x);
+    n += ok ? 1 : 0;
+    a[f] = ok ? x : __builtin_inff();
+  }
+  if (n == 0) {
+    med[item] = __builtin_nan("");
+    sd[item] = __builtin_nan("");
+    return;
+  }
+  bitonic_sort<NP>(a);
+  const int lo = (n - 1) >> 1, hi = n >> 1;
+  float mlo = 0.f, mhi = 0.f;
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i == lo) mlo = a[i];
+    if (i == hi) mhi = a[i];
+    s += i < n ? (double)a[i] : 0.0;
+  }
+  const double mean = s / (double)n;
+  double q = 0.0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const double d = (double)a[i] - mean;
+    q += i < n ? d * d : 0.0;
+  }
+  med[item] = lo == hi ? (double)mlo : ((double)mlo + (double)mhi) / 2.0;   // np.median: mean of the two middle values
+  sd[item] = sqrt(q / (double)n);
+}
+
+// std smear over the last Tf rows (trainer.py:280-282): a chain along the rows, one thread per variable
+__global__ void band_smear_kernel(double* __restrict__ sd, int R, int Tf, int V) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   for (int f = Tf - 1; f >= 1; --f) {
@@ -131,10 +206,15 @@ __global__ void band_finish_kernel(const double* __restrict__ med, double* __res
     const double add = sd[(long)(R - f - 1) * V + v] * gamma;
     sd[(long)(R - f) * V + v] = sd[(long)(R - f) * V + v] + add;
   }
-  for (int r = 0; r < R; ++r) {
-    const double m = med[(long)r * V + v], w = width * sd[(long)r * V + v];
-    lower[(long)r * V + v] = m - w;
-    upper[(long)r * V + v] = m + w;
+}
+
+// ... then the band, elementwise
+__global__ void band_finish_kernel(const double* __restrict__ med, const double* __restrict__ sd, long n, double width,
+                                   double* __restrict__ lower, double* __restrict__ upper) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double m = med[i], w = width * sd[i];
+    lower[i] = m - w;
+    upper[i] = m + w;
   }
 }
 
@@ -153,39 +233,116 @@ __global__ void hist_update_kernel(const float* __restrict__ pden, int B, int Tf
 
 // ---- K7 adjust ---------------------------------------------------------------------------------
 // variant 0: trainer.py:238-257, 1: cleaner.py:130-149, 2: predictor.py:106-125.
-// Sequential in p (each row uses the already-adjusted previous row), parallel over variables.
-__global__ void adjust_kernel(int variant, const double* __restrict__ seed, const double* __restrict__ reals,
-                              const double* __restrict__ preds, const int* __restrict__ masks,
-                              const double* __restrict__ lower, const double* __restrict__ upper, int n, int V,
-                              double a, double b, double* __restrict__ target) {
+// One row of the scan: the adjusted value of row p from its inputs and the adjusted value of row p-1.
+__device__ __forceinline__ double adjust_row(int variant, double value, double m, double pr, double lo, double up,
+                                             double prev, double a, double b) {
+  const double fill = a * pr + (1.0 - a) * prev;
+  if (variant == 0) {
+    value = (1.0 - m) * value + m * fill;
+    const double lm = (value < lo ? 1.0 : 0.0) * (1.0 - m);
+    const double um = (value > up ? 1.0 : 0.0) * (1.0 - m);
+    value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
+    value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
+  } else if (variant == 1) {
+    const double lm = value < lo ? 1.0 : 0.0, um = value > up ? 1.0 : 0.0;
+    value = (1.0 - m) * value + m * fill;
+    value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
+    value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
+  } else {
+    const double lm = value < lo ? 1.0 : 0.0, um = value > up ? 1.0 : 0.0;
+    value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
+    value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
+    value = (1.0 - m) * value + m * fill;
+  }
+  return value;
+}
+
+constexpr int ADJ_ROWS = 16;    // rows whose inputs are fetched together (the chain waits for memory once per batch)
+constexpr int ADJ_CHUNK = 64;   // rows per thread of the parallel form
+constexpr int ADJ_FLAGS = 64;
+__device__ int tb_adjust_flags[ADJ_FLAGS];   // per call: 1 if an input is not finite (host picks the slot round-robin)
+
+__global__ void adjust_flag_reset_kernel(int slot) { tb_adjust_flags[slot] = 0; }
+
+__global__ void adjust_flag_kernel(int slot, const double* __restrict__ seed, const double* __restrict__ reals,
+                                   const double* __restrict__ preds, const double* __restrict__ lower,
+                                   const double* __restrict__ upper, long n, int V) {
+  bool bad = false;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    bad = bad || !isfinite(reals[i]) || !isfinite(preds[i]) || !isfinite(lower[i]) || !isfinite(upper[i]);
+    if (i < V) bad = bad || !isfinite(seed[i]);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&tb_adjust_flags[slot], 1);
+}
+
+// Sequential in p (each row uses the already-adjusted previous row), parallel over variables: the literal
+// order of the reference.  Runs only when an input is not finite (a NaN then travels down the column through
+// every row, masked or not, exactly as in the reference's arithmetic).
+__global__ __launch_bounds__(64) void adjust_kernel(int slot, int variant, const double* __restrict__ seed,
+                                                    const double* __restrict__ reals, const double* __restrict__ preds,
+                                                    const int* __restrict__ masks, const double* __restrict__ lower,
+                                                    const double* __restrict__ upper, int n, int V, double a, double b,
+                                                    double* __restrict__ target) {
+  if (slot >= 0 && tb_adjust_flags[slot] == 0) return;
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= V) return;
   double prev = seed[v];
-  for (int p = 0; p < n; ++p) {
-    const long o = (long)p * V + v;
-    double value = reals[o];
-    const double m = (double)masks[o];
-    const double pr = preds[o], lo = lower[o], up = upper[o];
-    const double fill = a * pr + (1.0 - a) * prev;
-    if (variant == 0) {
-      value = (1.0 - m) * value + m * fill;
-      const double lm = (value < lo ? 1.0 : 0.0) * (1.0 - m);
-      const double um = (value > up ? 1.0 : 0.0) * (1.0 - m);
-      value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
-      value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
-    } else if (variant == 1) {
-      const double lm = value < lo ? 1.0 : 0.0, um = value > up ? 1.0 : 0.0;
-      value = (1.0 - m) * value + m * fill;
-      value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
-      value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
-    } else {
-      const double lm = value < lo ? 1.0 : 0.0, um = value > up ? 1.0 : 0.0;
-      value = (1.0 - lm) * value + lm * (b * pr + (1.0 - b) * value);
-      value = (1.0 - um) * value + um * (b * pr + (1.0 - b) * value);
-      value = (1.0 - m) * value + m * fill;
+  for (int p0 = 0; p0 < n; p0 += ADJ_ROWS) {
+    double rv_[ADJ_ROWS], pr_[ADJ_ROWS], lo_[ADJ_ROWS], up_[ADJ_ROWS];
+    int mk_[ADJ_ROWS];
+#pragma unroll
+    for (int i = 0; i < ADJ_ROWS; ++i) {
+      const long o = (long)(p0 + i < n ? p0 + i : n - 1) * V + v;
+      rv_[i] = reals[o]; pr_[i] = preds[o]; lo_[i] = lower[o]; up_[i] = upper[o]; mk_[i] = masks[o];
     }
-    target[o] = value;
-    prev = value;
+#pragma unroll
+    for (int i = 0; i < ADJ_ROWS; ++i) {
+      const int p = p0 + i;
+      if (p >= n) continue;
+      prev = adjust_row(variant, rv_[i], (double)mk_[i], pr_[i], lo_[i], up_[i], prev, a, b);
+      target[(long)p * V + v] = prev;
+    }
+  }
+}
+
+// The same scan, parallel over chunks of rows.  A row's value depends on the previous row's only through
+// m * fill: with finite inputs a row whose mask is 0 does not depend on it at all (0 * fill adds nothing).
+// So the thread of (chunk, variable) walks back from its first row to the nearest row with mask 0 (or to the
+// seed), and replays the reference's arithmetic from there, in the reference's order: the same operations
+// on the same operands as the sequential form, hence the same values (up to the sign of a zero).
+__global__ __launch_bounds__(64) void adjust_chunk_kernel(int slot, int variant, const double* __restrict__ seed,
+                                                          const double* __restrict__ reals,
+                                                          const double* __restrict__ preds, const int* __restrict__ masks,
+                                                          const double* __restrict__ lower,
+                                                          const double* __restrict__ upper, int n, int V, double a,
+                                                          double b, double* __restrict__ target) {
+  if (tb_adjust_flags[slot] != 0) return;
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const int p0 = blockIdx.y * ADJ_CHUNK;
+  int q = p0 - 1;
+  while (q >= 0 && masks[(long)q * V + v] != 0) --q;
+  double prev = q < 0 ? seed[v] : 0.0;   // row q (mask 0) does not look at it
+  for (int p = q < 0 ? 0 : q; p < p0; ++p) {
+    const long o = (long)p * V + v;
+    prev = adjust_row(variant, reals[o], (double)masks[o], preds[o], lower[o], upper[o], prev, a, b);
+  }
+  const int pend = p0 + ADJ_CHUNK < n ? p0 + ADJ_CHUNK : n;
+  for (int pb = p0; pb < pend; pb += ADJ_ROWS) {
+    double rv_[ADJ_ROWS], pr_[ADJ_ROWS], lo_[ADJ_ROWS], up_[ADJ_ROWS];
+    int mk_[ADJ_ROWS];
+#pragma unroll
+    for (int i = 0; i < ADJ_ROWS; ++i) {
+      const long o = (long)(pb + i < pend ? pb + i : pend - 1) * V + v;
+      rv_[i] = reals[o]; pr_[i] = preds[o]; lo_[i] = lower[o]; up_[i] = upper[o]; mk_[i] = masks[o];
+    }
+#pragma unroll
+    for (int i = 0; i < ADJ_ROWS; ++i) {
+      const int p = pb + i;
+      if (p >= pend) continue;
+      prev = adjust_row(variant, rv_[i], (double)mk_[i], pr_[i], lo_[i], up_[i], prev, a, b);
+      target[(long)p * V + v] = prev;
+    }
   }
 }
 
@@ -280,10 +437,20 @@ int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in
   const size_t lds = (size_t)BAND_WAVES * Tf * sizeof(float);
   if (lds > 60 * 1024) return tb_set_error(TB_ERR_UNSUPPORTED, "band_update: forecast_len %d too long", Tf);
   tb_prof_begin(TB_K_BAND, s);
-  hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nitems + BAND_WAVES - 1) / BAND_WAVES)), dim3(64 * BAND_WAVES),
-                     lds, s, pden, B, Tf, V, hist_in, nhist, med, sd);
-  TB_LAUNCH_CHECK("band_kernel");
-  hipLaunchKernelGGL(band_finish_kernel, dim3((V + 63) / 64), dim3(64), 0, s, med, sd, R, Tf, V, band_width, lower,
+  if (Tf <= BAND_T_MAX) {
+    const dim3 g((unsigned)((nitems + 255) / 256));
+    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+    TB_LAUNCH_CHECK("band_sort_kernel");
+  } else {
+    hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nitems + BAND_WAVES - 1) / BAND_WAVES)), dim3(64 * BAND_WAVES),
+                       lds, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+    TB_LAUNCH_CHECK("band_kernel");
+  }
+  hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
+  TB_LAUNCH_CHECK("band_smear_kernel");
+  hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems)), dim3(256), 0, s, med, sd, nitems, band_width, lower,
                      upper);
   TB_LAUNCH_CHECK("band_finish_kernel");
   hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for((long)(Tf - 1) * Tf * V)), dim3(256), 0, s, pden, B, Tf, V,
@@ -301,9 +468,22 @@ int tb_adjust_scan(int variant, const double* seed, const double* reals, const d
   if (variant < 0 || variant > 2) return tb_set_error(TB_ERR_ARG, "adjust_scan: variant must be 0, 1 or 2");
   if (!seed || !reals || !preds || !masks || !lower || !upper || !target)
     return tb_set_error(TB_ERR_ARG, "adjust_scan: null pointer");
-  hipLaunchKernelGGL(adjust_kernel, dim3((V + 63) / 64), dim3(64), 0, s, variant, seed, reals, preds, masks, lower,
+  if (n <= ADJ_CHUNK) {   // short: the sequential form as it is
+    hipLaunchKernelGGL(adjust_kernel, dim3((V + 63) / 64), dim3(64), 0, s, -1, variant, seed, reals, preds, masks,
+                       lower, upper, n, V, missing_gamma, anomaly_gamma, target);
+    TB_LAUNCH_CHECK("adjust_kernel");
+    return TB_OK;
+  }
+  static std::atomic<unsigned> next_slot{0};
+  const int slot = (int)(next_slot.fetch_add(1) % ADJ_FLAGS);
+  hipLaunchKernelGGL(adjust_flag_reset_kernel, dim3(1), dim3(1), 0, s, slot);
+  hipLaunchKernelGGL(adjust_flag_kernel, dim3(grid_for((long)n * V)), dim3(256), 0, s, slot, seed, reals, preds, lower,
+                     upper, (long)n * V, V);
+  hipLaunchKernelGGL(adjust_chunk_kernel, dim3((V + 63) / 64, (n + ADJ_CHUNK - 1) / ADJ_CHUNK), dim3(64), 0, s, slot,
+                     variant, seed, reals, preds, masks, lower, upper, n, V, missing_gamma, anomaly_gamma, target);
+  hipLaunchKernelGGL(adjust_kernel, dim3((V + 63) / 64), dim3(64), 0, s, slot, variant, seed, reals, preds, masks, lower,
                      upper, n, V, missing_gamma, anomaly_gamma, target);
-  TB_LAUNCH_CHECK("adjust_kernel");
+  TB_LAUNCH_CHECK("adjust kernels");
   return TB_OK;
 }
 
