@@ -16,23 +16,32 @@ namespace {
 // window w: i = starts ? starts[w] : first + w*stride;
 //   enc[w] = series[i-To : i, :]            (To*E contiguous floats)
 //   dec[w] = series[i : i+Tf, target_cols]
-__global__ void window_gather_kernel(const float* __restrict__ series, int E, const long* __restrict__ starts,
-                                     long first, long stride, int nwin, int To, int Tf,
-                                     const int* __restrict__ tcols, int V, float* __restrict__ enc,
-                                     float* __restrict__ dec) {
-  const long ne = (long)To * E, nd = (long)Tf * V;
-  const long per = ne + nd;
-  const long total = per * nwin;
-  for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-    const int w = (int)(g / per);
-    const long r = g - (long)w * per;
+// blockIdx.y strides the windows; the threads of a block copy one window's To*E encoder floats (16 bytes per
+// thread when VEC: E % 4 == 0 and a 16-byte aligned series make every window start aligned) and gather its
+// Tf*V decoder floats.  32-bit index arithmetic inside a window.
+template <bool VEC>
+__global__ __launch_bounds__(256) void window_gather_kernel(const float* __restrict__ series, int E,
+                                                            const long* __restrict__ starts, long first, long stride,
+                                                            int nwin, int To, int Tf, const int* __restrict__ tcols,
+                                                            int V, float* __restrict__ enc, float* __restrict__ dec) {
+  const int ne = To * E, nd = Tf * V;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  for (int w = blockIdx.y; w < nwin; w += gridDim.y) {
     const long i = starts ? starts[w] : first + (long)w * stride;
-    if (r < ne) {
-      enc[(long)w * ne + r] = series[(i - To) * E + r];
+    const float* src = series + (i - To) * E;
+    float* e = enc + (long)w * ne;
+    if (VEC) {
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+      f32x4* e4 = reinterpret_cast<f32x4*>(e);
+      for (int r = tid; r < ne / 4; r += nthr) e4[r] = s4[r];
     } else {
-      const long k = r - ne;
-      const int f = (int)(k / V), v = (int)(k % V);
-      dec[(long)w * nd + k] = series[(i + f) * E + tcols[v]];
+      for (int r = tid; r < ne; r += nthr) e[r] = src[r];
+    }
+    const float* fut = series + i * E;
+    float* d = dec + (long)w * nd;
+    for (int k = tid; k < nd; k += nthr) {
+      const int f = k / V, v = k - f * V;
+      d[k] = fut[(long)f * E + tcols[v]];
     }
   }
 }
@@ -403,10 +412,18 @@ int tb_window_gather(const float* series, long series_len, int E, const long* st
       return tb_set_error(TB_ERR_ARG, "window_gather: windows [%ld..%ld] leave the series (len %ld)", first, last,
                           series_len);
   }
-  const long total = ((long)To * E + (long)Tf * V) * nwin;
+  if ((long)To * E > 0x7FFFFFFFl || (long)Tf * V > 0x7FFFFFFFl) return tb_set_error(TB_ERR_UNSUPPORTED, "window_gather: window too large");
+  const long per = (long)To * E > (long)Tf * V ? (long)To * E : (long)Tf * V;
+  const bool vec = (E & 3) == 0 && (reinterpret_cast<uintptr_t>(series) & 15) == 0 && (reinterpret_cast<uintptr_t>(enc) & 15) == 0;
+  int bx = (int)(((vec ? per / 4 : per) + 255) / 256);
+  if (bx > 16) bx = 16;
+  if (bx < 1) bx = 1;
+  const dim3 grid(bx, nwin < 32768 ? nwin : 32768);
   tb_prof_begin(TB_K_GATHER, s);
-  hipLaunchKernelGGL(window_gather_kernel, dim3(grid_for(total)), dim3(256), 0, s, series, E, starts, first, stride,
-                     nwin, To, Tf, target_cols, V, enc, dec);
+  if (vec) hipLaunchKernelGGL(window_gather_kernel<true>, grid, dim3(256), 0, s, series, E, starts, first, stride, nwin, To,
+                              Tf, target_cols, V, enc, dec);
+  else hipLaunchKernelGGL(window_gather_kernel<false>, grid, dim3(256), 0, s, series, E, starts, first, stride, nwin, To,
+                          Tf, target_cols, V, enc, dec);
   TB_LAUNCH_CHECK("window_gather_kernel");
   tb_prof_end(TB_K_GATHER, s);
   return TB_OK;
