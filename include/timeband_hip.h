@@ -117,8 +117,10 @@ int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, doub
  * tb_denormalize: source/dataset.py:229-242 (fp32 -> fp64 arithmetic -> fp32).
  * tb_band_update: predicts(), source/trainer.py:266-287 = source/cleaner.py:158-179 =
  *   source/predictor.py:134-155.
- *   pden (B,Tf,V) denormalised predictions; hist_in/hist_out (Tf-1,Tf,V) the predictions of the last
- *   Tf-1 windows before/after this batch (distinct buffers; nhist = valid windows in hist_in);
+ *   pden (B,Tf,V) predictions; hist_in/hist_out (Tf-1,Tf,V) the predictions of the last Tf-1 windows
+ *   before/after this batch (distinct buffers; nhist = valid windows in hist_in);
+ *   dmin/dmax (V) float64, both or neither: if given, pden and the history hold NORMALISED predictions
+ *   and tb_denormalize's arithmetic is applied as they are read (one pass less over the batch);
  *   med/sd/lower/upper (B+Tf-1,V) float64.
  * tb_adjust_scan: adjust(); variant 0 source/trainer.py:238-257, 1 source/cleaner.py:130-149,
  *   2 source/predictor.py:106-125.
@@ -129,7 +131,8 @@ int tb_window_gather(const float* series, long series_len, int E, const long* st
                      void* stream);
 int tb_denormalize(const float* x, long n, int V, const double* dmin, const double* dmax, float* out, void* stream);
 int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
-                   double band_width, double* med, double* sd, double* lower, double* upper, void* stream);
+                   const double* dmin, const double* dmax, double band_width, double* med, double* sd, double* lower,
+                   double* upper, void* stream);
 int tb_adjust_scan(int variant, const double* seed, const double* reals, const double* preds, const int* masks,
                    const double* lower, const double* upper, int n, int V, double missing_gamma,
                    double anomaly_gamma, double* target, void* stream);

@@ -48,6 +48,12 @@ __global__ __launch_bounds__(256) void window_gather_kernel(const float* __restr
 
 // ---- denormalise (dataset.py:229-242) ----------------------------------------------------------
 // fp32 0.5*(x+1); times fp64 (max-min); plus fp64 min; rounded back to fp32
+__device__ __forceinline__ float denorm1(float x, double mn, double mx) {
+  const float half = 0.5f * (x + 1.0f);
+  const double t = (double)half * (mx - mn);
+  return (float)(t + mn);
+}
+
 __global__ void denorm_kernel(const float* __restrict__ x, long n, int V, const double* __restrict__ dmin,
                               const double* __restrict__ dmax, float* __restrict__ out) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -67,6 +73,7 @@ constexpr int BAND_WAVES = 4;
 
 __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __restrict__ pden, int B, int Tf, int V,
                                                                const float* __restrict__ hist, int nhist,
+                                                               const double* __restrict__ dmin, const double* __restrict__ dmax,
                                                                double* __restrict__ med, double* __restrict__ sd) {
   extern __shared__ float vals_all[];   // [BAND_WAVES][Tf]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __re
         const int w = r - f;
         if (w >= 0 && w < B) { x = pden[((long)w * Tf + f) * V + v]; ok = true; }
         else if (w < 0 && -w <= nhist) { x = hist[((long)(Tf - 1 + w) * Tf + f) * V + v]; ok = true; }
+        if (ok && dmin) x = denorm1(x, dmin[v], dmax[v]);
         ok = ok && !isnan(x);
       }
       const unsigned long long m = __ballot(ok);
@@ -161,6 +169,7 @@ __device__ __forceinline__ void bitonic_sort(float (&a)[NP]) {
 template <int NP>
 __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V,
                                                         const float* __restrict__ hist, int nhist,
+                                                        const double* __restrict__ dmin, const double* __restrict__ dmax,
                                                         double* __restrict__ med, double* __restrict__ sd) {
   const long item = (long)blockIdx.x * 256 + threadIdx.x;
   const long nitems = (long)(B + Tf - 1) * V;
@@ -168,6 +177,7 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
   const int r = (int)(item / V), v = (int)(item % V);
   float a[NP];
   int n = 0;
+  const double mn = dmin ? dmin[v] : 0.0, mx = dmin ? dmax[v] : 0.0;
 #pragma unroll
   for (int f = 0; f < NP; ++f) {
     const int w = r - f;
@@ -176,6 +186,7 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
       if (w >= 0 && w < B) x = pden[((long)w * Tf + f) * V + v];
       else if (w < 0 && -w <= nhist) x = hist[((long)(Tf - 1 + w) * Tf + f) * V + v];
     }
+    if (dmin) x = denorm1(x, mn, mx);   // NaN stays NaN
     const bool ok = !isnan(x);
     n += ok ? 1 : 0;
     a[f] = ok ? x : __builtin_inff();
@@ -442,13 +453,15 @@ int tb_denormalize(const float* x, long n, int V, const double* dmin, const doub
 // the last Tf-1 windows before / after this batch (distinct buffers), nhist = valid windows in hist_in.
 // med/sd/lower/upper: (B+Tf-1, V) float64 outputs (sd is returned AFTER the smear).
 int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
-                   double band_width, double* med, double* sd, double* lower, double* upper, void* stream) {
+                   const double* dmin, const double* dmax, double band_width, double* med, double* sd, double* lower,
+                   double* upper, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0) return TB_OK;
   if (Tf < 2) return tb_set_error(TB_ERR_ARG, "band_update: forecast_len must be >= 2 (the reference divides by Tf-1)");
   if (!pden || !hist_in || !hist_out || !med || !sd || !lower || !upper || hist_in == hist_out)
     return tb_set_error(TB_ERR_ARG, "band_update: bad pointer");
   if (nhist < 0 || nhist > Tf - 1) return tb_set_error(TB_ERR_ARG, "band_update: nhist out of range");
+  if ((dmin == nullptr) != (dmax == nullptr)) return tb_set_error(TB_ERR_ARG, "band_update: dmin and dmax go together");
   const int R = B + Tf - 1;
   const long nitems = (long)R * V;
   const size_t lds = (size_t)BAND_WAVES * Tf * sizeof(float);
@@ -456,13 +469,13 @@ int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in
   tb_prof_begin(TB_K_BAND, s);
   if (Tf <= BAND_T_MAX) {
     const dim3 g((unsigned)((nitems + 255) / 256));
-    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
-    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
-    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
+    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
+    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
     TB_LAUNCH_CHECK("band_sort_kernel");
   } else {
     hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nitems + BAND_WAVES - 1) / BAND_WAVES)), dim3(64 * BAND_WAVES),
-                       lds, s, pden, B, Tf, V, hist_in, nhist, med, sd);
+                       lds, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
     TB_LAUNCH_CHECK("band_kernel");
   }
   hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);

@@ -440,8 +440,11 @@ def denormalize(x, dmin, dmax):
     return out
 
 
-def band_update(pden, hist_in, nhist, hist_out, band_width):
+def band_update(pden, hist_in, nhist, hist_out, band_width, dmin=None, dmax=None):
+    """dmin / dmax given: `pden` and the history hold NORMALISED predictions, denormalised as they are read."""
     _need_cuda(pden, hist_in, hist_out)
+    if dmin is not None:
+        dmin, dmax = _c(dmin, torch.float64), _c(dmax, torch.float64)
     pden = _f32c(pden)
     B, Tf, V = pden.shape
     for h in (hist_in, hist_out):
@@ -450,7 +453,8 @@ def band_update(pden, hist_in, nhist, hist_out, band_width):
     R = B + Tf - 1
     mk = lambda: torch.empty(R, V, dtype=torch.float64, device=pden.device)
     med, sd, lower, upper = mk(), mk(), mk(), mk()
-    _lib.call("tb_band_update", _ptr(pden), B, Tf, V, _ptr(hist_in), int(nhist), _ptr(hist_out), float(band_width),
+    _lib.call("tb_band_update", _ptr(pden), B, Tf, V, _ptr(hist_in), int(nhist), _ptr(hist_out), _ptr(dmin), _ptr(dmax),
+              float(band_width),
               _ptr(med), _ptr(sd), _ptr(lower), _ptr(upper), _stream())
     return med, lower, upper
 

@@ -41,8 +41,9 @@ class BandAdjust:
     def step(self, fake_y):
         d = self.ds
         B, Tf, V = fake_y.shape
-        pden = ops.denormalize(fake_y.detach(), d.dmin_dev, d.dmax_dev)
-        preds, lower, upper = ops.band_update(pden, self.hist[self.cur], self.nhist, self.hist[self.cur ^ 1], self.w)
+        # the history holds normalised predictions: the band kernel denormalises as it gathers
+        preds, lower, upper = ops.band_update(fake_y.detach(), self.hist[self.cur], self.nhist, self.hist[self.cur ^ 1],
+                                              self.w, d.dmin_dev, d.dmax_dev)
         self.cur ^= 1
         self.nhist = min(Tf - 1, self.nhist + B)
         n = B + Tf - 1
