@@ -103,3 +103,50 @@ def test_init_matches_reference_rng_order(golden_dir):
             assert np.array_equal(v.numpy(), z[f"init.netD.{k}"]), k
         for k, v in netG.state_dict().items():
             assert np.array_equal(v.numpy(), z[f"init.netG.{k}"]), k
+
+
+def test_genb_data_front_end_on_cpu(tmp_path):
+    """timeband_amd.data.TIMEBANDData (reference source/data.py): directory layout, artefacts, time features
+    prepended in the order given, min-max normalisation from the saved minmax.csv, and windows equal to
+    the reference's slicing loop (data.py:139-143), here restated literally."""
+    import numpy as np
+    import pandas as pd
+    import torch
+    from timeband_amd import synthetic
+    from timeband_amd.data import TIMEBANDData
+    V, To, Tf, N = 3, 6, 4, 120
+    base = str(tmp_path)
+    synthetic.write_csv(os.path.join(base, "origin"), "s", N, V, seed=3, missing_rate=0.05)
+    d = TIMEBANDData(basedir=base, filename="s", targets=[f"v{i}" for i in range(V)], drops=[], fill_timegap=False,
+                     time_index=["Date"], time_encode=["weekday", "hour"], split_size=0.75, observed_len=To,
+                     forecast_len=Tf, device="cpu")
+    assert (d.encode_dims, d.decode_dims) == (V + 2, V)
+    frame = d.init_dataset()
+    for f in (d.target_path, d.minmax_path, d.missing_path):
+        assert os.path.exists(f)
+    assert list(d.observed.columns[:2]) == ["hour", "weekday"]        # each feature is prepended
+    miss = pd.read_csv(d.missing_path)
+    assert int(miss[[f"v{i}" for i in range(V)]].to_numpy().sum()) > 0
+    trainset, validset = d.prepare_trainset(frame)
+    # the reference's loop over the same normalised frame
+    raw = pd.read_csv(d.target_path, parse_dates=["Date"]).set_index("Date").ffill().bfill().replace(np.nan, 0)
+    full = d.parse_timeinfo(raw)
+    mm = pd.read_csv(d.minmax_path, index_col=["Feats"])
+    full = 2 * ((full - mm["min"]) / (mm["max"] - mm["min"])) - 1
+    x, y = full.to_numpy(), full[[f"v{i}" for i in range(V)]].to_numpy()
+    obs, fut = [], []
+    for i in range(To, len(full) - Tf + 1):
+        obs.append(x[i - To:i])
+        fut.append(y[i:i + Tf])
+    split = min(int(len(full) * 0.75), len(full) - To - Tf)
+    assert len(trainset) == split and len(trainset) + len(validset) == len(obs)
+    np.testing.assert_allclose(np.concatenate([trainset.encoded, validset.encoded]), np.array(obs), rtol=0, atol=0)
+    np.testing.assert_allclose(np.concatenate([trainset.decoded, validset.decoded]), np.array(fut), rtol=0, atol=0)
+    e0, d0 = trainset[0]
+    assert e0.dtype == torch.float32 and e0.shape == (To, V + 2) and d0.shape == (Tf, V)
+    xs, ys = d.get_random(trainset)
+    assert xs.shape == (Tf, To, V + 2) and ys.shape == (Tf, Tf, V)
+    assert torch.allclose(d.delta, d.decode_max - d.decode_min)
+    sub_frame = pd.read_csv(d.target_path, parse_dates=["Date"]).iloc[-To - Tf:]
+    predset = d.prepare_predset(sub_frame)
+    assert len(predset) == Tf and predset.shape() == (Tf, To, V + 2)
