@@ -56,6 +56,9 @@ __device__ __forceinline__ void tb_store_agent_u64(unsigned long long* p, unsign
 __device__ __forceinline__ unsigned tb_load_agent_u32(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned long long tb_load_agent_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- split-precision bf16 operands ("bf16x3") ------------------------------------------------
 // An fp32 value x is carried as two bf16 values hi = bf16(x), lo = bf16(x - hi) (x = hi + lo to

@@ -38,6 +38,8 @@
 // no global exchange at all.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
+#include <random>
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
@@ -79,8 +81,9 @@ struct FwdArgs {
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
-  float* ring;         // [nclusters][3][MT*16][H] exchange ring (NCL > 1) of {bf16 hi | bf16 lo} words, sentinel-armed before the launch
-  unsigned* hello;     // [nclusters][NCL] start-up handshake words, sentinel-armed before the launch
+  float* ring;         // [nclusters][3][MT*16][H] exchange ring (NCL > 1) of {bf16 hi | bf16 lo} words; every member arms its own slices at start-up
+  unsigned long long* hello;   // [nclusters][NCL] start-up handshake tags
+  unsigned long long epoch;    // this launch's handshake epoch
   int* err;            // [4] sticky error words
   int B, T;
   int b_begin;         // first batch row of this launch
@@ -104,18 +107,25 @@ __device__ __forceinline__ void cluster_decode(int NCL, int& cl, int& j) {
   }
 }
 
-// Start-up handshake of a cluster.  Every member publishes the id of the XCD it runs on with a
-// write-through (sc1) store and reads the others' (sc1 loads work across XCDs).  Returns 1 if ALL
-// members share one XCD -- then they share one L2, and the per-step exchange may use plain stores
-// (which stay in that L2: a third of the hand-off latency of write-through stores) --, 0 if not
-// (the exchange then uses write-through stores, valid under any placement), -1 on timeout.
+// Start-up handshake of a cluster.  Every member publishes a tag {launch epoch | id of the XCD it runs on}
+// with a write-through (sc1) store and reads the others' (sc1 loads work across XCDs) until they carry THIS
+// launch's epoch.  The epoch is unique per launch (a random 60-bit base per process plus a counter), so
+// whatever the handshake words held before -- an earlier launch's tags, another layout's data, fresh
+// memory -- cannot be mistaken for it, and nothing has to be cleared before a launch.
+// A member sends its tag only after the stores that ARM ITS OWN PART of the exchange area have been
+// acknowledged (callers: sc1 stores, then vmcnt(0), then this function, which starts with a barrier), so a
+// member that has seen every tag knows the whole area is armed.
+// Returns 1 if ALL members share one XCD -- then they share one L2, and the per-step exchange may use
+// plain stores (which stay in that L2: a third of the hand-off latency of write-through stores) --, 0 if
+// not (the exchange then uses write-through stores, valid under any placement), -1 on timeout.
 // "all equal" is symmetric, so every member takes the same decision.
-__device__ __forceinline__ int cluster_hello(unsigned* hello, int NCL, int j, unsigned long long timeout, int* err,
-                                             int* s_word) {
+__device__ __forceinline__ int cluster_hello(unsigned long long* hello, unsigned long long epoch, int NCL, int j,
+                                             unsigned long long timeout, int* err, int* s_word) {
+  __syncthreads();   // every thread's arming stores are acknowledged
   unsigned myx;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(myx));
   myx &= 0xFu;
-  if (threadIdx.x == 0) tb_store_agent_u32(hello + j, myx);
+  if (threadIdx.x == 0) tb_store_agent_u64(hello + j, (epoch << 4) | myx);
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     unsigned v = myx;
@@ -123,15 +133,15 @@ __device__ __forceinline__ int cluster_hello(unsigned* hello, int NCL, int j, un
     for (int m = lane; m < NCL; m += 64) {
       const unsigned long long t0 = wall_clock64();
       unsigned it = 0;
-      unsigned w;
-      while ((w = tb_load_agent_u32(hello + m)) == 0xFFFFFFFFu) {
+      unsigned long long w;
+      while (((w = tb_load_agent_u64(hello + m)) >> 4) != epoch) {
         __builtin_amdgcn_s_sleep(2);
         if ((++it & 1023u) == 0 && wall_clock64() - t0 > timeout) {
           ok = false;
           break;
         }
       }
-      if (w != myx) v = 0xFFFFFFF0u;
+      if ((unsigned)(w & 0xFu) != myx) v = 0xFFFFFFF0u;
     }
     const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
     const bool all_eq = __builtin_amdgcn_ballot_w64(v != myx) == 0ull;
@@ -237,6 +247,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
   if (tid == 0) *s_dead = 0;
   for (int i = tid; i < MT * 16 * LDH; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;   // hi and lo, pad included
+  if (NCL > 1) {
+    // arm this member's slices of the three ring slots (write-through: the members may sit on different
+    // XCDs); acknowledged before the handshake tag goes out, see cluster_hello()
+    float* rg = a.ring + (size_t)cl * 3 * RS;
+    const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+    constexpr int PER = MT * 16 * (US / 4);
+    const __amdgpu_buffer_rsrc_t rA_ = __builtin_amdgcn_make_buffer_rsrc((void*)rg, 0, 3 * RS * 4, kBufFlags);
+    for (int i = tid; i < 3 * PER; i += 256) {
+      const int slot = i / PER, r = i % PER, row = r / (US / 4), c4 = r % (US / 4);
+      stg4<kSC1>(rA_, (long)slot * RS + (long)row * H + j * US + c4 * 4, arm);
+    }
+  }
   // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
   int vrows = a.B - b0;
   if (vrows > 16 * MT) vrows = 16 * MT;
@@ -275,7 +297,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   }
   bool same_l2 = false;
   if (NCL > 1) {
-    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, NCL, j, a.timeout_ticks, a.err, s_word);   // has a barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the arming stores (and the loads above) have landed
+    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, a.epoch, NCL, j, a.timeout_ticks, a.err, s_word);   // has barriers
     if (hs < 0) return;
     same_l2 = hs == 1;
   } else {
@@ -564,7 +587,8 @@ struct BwdArgs {
   const float* Whh;    // [4H][H]
   float* X;            // [nclusters][3][NCL consumers][NCL producers][MT*16][US] exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
-  unsigned* hello;     // [nclusters][NCL] start-up handshake words, sentinel-armed before the launch
+  unsigned long long* hello;   // [nclusters][NCL] start-up handshake tags
+  unsigned long long epoch;    // this launch's handshake epoch
   int* err;
   int B, T;
   int b_begin;
@@ -614,6 +638,17 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cst + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)Xc, 0, NCL > 1 ? 3 * XSLAB * 4 : 0, kBufFlags);
+  if (NCL > 1) {
+    // arm the part of the three slabs this member CONSUMES ([slab][j][every producer][rows][units], one
+    // contiguous run per slab; its own never-written slot included); write-through, acknowledged before
+    // the handshake tag goes out, see cluster_hello()
+    const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+    constexpr int PER = NCL * MT * 16 * US / 4;   // 16-byte pieces per slab
+    for (int i = tid; i < 3 * PER; i += 256) {
+      const int slab = i / PER, r = i % PER;
+      stg4<kSC1>(rX, (long)slab * XSLAB + (long)j * NCL * MT * 16 * US + (long)r * 4, arm);
+    }
+  }
 
   // W_hh fragments (A operand of the transposed product dh^T = W_hh^T . dgates^T), split bf16 hi/lo:
   // A[m][k] = W_hh[grow(k)][n0 + m], k = s*32 + q*8 + i, grow(k) = (k/US)*H + j*US + k%US
@@ -660,7 +695,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   }
   bool same_l2 = false;
   if (NCL > 1) {
-    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, NCL, j, a.timeout_ticks, a.err, s_word);   // has a barrier
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the arming stores (and the first step's stash) have landed
+    const int hs = cluster_hello(a.hello + (size_t)cl * NCL, a.epoch, NCL, j, a.timeout_ticks, a.err, s_word);   // has barriers
     if (hs < 0) return;
     same_l2 = hs == 1;
   } else {
@@ -1017,9 +1053,19 @@ bool tile_fits_descriptor(const Plan& p, int T, int H) {
 }
 
 // workspace carve: [hello | exchange (fwd: h ring, bwd: dh slabs) | bias sum | dbpart | gemm split-k slabs]
-// hello + exchange are contiguous: one 0xFF fill arms both before a launch
+// Nothing in it has to be initialised: the kernels arm the exchange area themselves and the handshake
+// tags carry a per-launch epoch.
+unsigned long long next_epoch() {
+  static const unsigned long long base = []() {
+    std::random_device rd;
+    return ((unsigned long long)rd() << 32) ^ (unsigned long long)rd();
+  }();
+  static std::atomic<unsigned long long> counter{0};
+  return (base + counter.fetch_add(1)) & 0x0FFFFFFFFFFFFFFFull;   // 60 bits: the tag keeps 4 for the XCD id
+}
+
 struct Carve {
-  unsigned* hello; size_t hello_bytes;
+  unsigned long long* hello; size_t hello_bytes;
   float* X; size_t x_bytes;
   float* bsum;
   float* dbpart;
@@ -1030,7 +1076,7 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   size_t off = 0;
   const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
-  const size_t hello_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * p.NCL * sizeof(unsigned), 256) : 0;
+  const size_t hello_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * p.NCL * sizeof(unsigned long long), 256) : 0;
   // rings of 3 slots per cluster: forward rows x H floats (h_t all-gather), backward NCL x rows x H
   // (one partial of dh per producer, reduce-scatter)
   const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * p.rows_per_cluster * H * sizeof(float), 256) : 0;
@@ -1038,7 +1084,7 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   (void)in_dim;
   const size_t gemm_bytes = bwd ? tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
-  if (c) { c->hello = reinterpret_cast<unsigned*>(base + off); c->hello_bytes = hello_bytes; }
+  if (c) { c->hello = reinterpret_cast<unsigned long long*>(base + off); c->hello_bytes = hello_bytes; }
   off += hello_bytes;
   if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
   off += x_bytes;
@@ -1108,7 +1154,7 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
     a.ring = c.X;
     a.hello = c.hello;
-    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.hello, 0xFF, c.hello_bytes + c.x_bytes, s));   // arm handshake + ring
+    a.epoch = next_epoch();
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
@@ -1153,7 +1199,7 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
     a.cl_begin = c0;
-    if (p.NCL > 1) TB_HIP(hipMemsetAsync(c.hello, 0xFF, c.hello_bytes + c.x_bytes, s));   // arm handshake + slabs
+    a.epoch = next_epoch();
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
     if (c0 == 0) tb_prof_begin(TB_K_LSTM_BWD, s, 4.0 * B * T * (2.0 * in_dim + 6.0 * H));
