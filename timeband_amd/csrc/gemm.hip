@@ -34,6 +34,7 @@ struct GemmArgs {
   const float* B;
   float* C;
   const float* bias;
+  const float* bias2;   // optional second bias vector: the epilogue adds (bias + bias2)
   int M, N, K;
   long lda, ldb, ldc;
   int act;
@@ -172,9 +173,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     f32x4 bv;
     {
       const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (a.bias && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb2_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (a.bias2 && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
       const int nb = n0 + wn * CW + (lane % (CW / 4)) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, (nb + r) * 4, 0, 0));
+      for (int r = 0; r < 4; ++r)
+        bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, (nb + r) * 4, 0, 0)) +
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2_, (nb + r) * 4, 0, 0));
       // wait HERE (the operand tile loaded before it is needed now anyway): left to the compiler, the wait
       // lands at the first use in the epilogue as vmcnt(0) and drains the stores issued before it
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -285,13 +289,13 @@ __global__ void splitk_group_kernel(float* __restrict__ slab, int splits, long t
 
 // C[m][n] = act(sum over z = 0, zstep, 2*zstep, ... < splits of slab[z][m][n] + bias[n])
 __global__ void splitk_final_kernel(const float* __restrict__ slab, int splits, int zstep, int M, int N, float* C,
-                                    long ldc, const float* bias, int act, int accumulate) {
+                                    long ldc, const float* bias, const float* bias2, int act, int accumulate) {
   const long total = (long)M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int z = 0; z < splits; z += zstep) s += slab[(size_t)z * total + i];
     const int m = (int)(i / N), n = (int)(i % N);
-    if (bias) s += bias[n];
+    if (bias || bias2) s += (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f);
     if (act == 1) s = tanhf(s);
     else if (act == 2) s = tb_sigmoid(s);
     if (accumulate) s += C[(long)m * ldc + n];
@@ -334,15 +338,27 @@ size_t tb_gemm_ws_bytes() { return (size_t)3 * tb_num_cus() * 128 * 128 * sizeof
 // transA: 0 -> A is [M][K]; 1 -> A is [K][M].   transB: 0 -> B is [N][K]; 1 -> B is [K][N].
 // accumulate: C += the product (weight gradients added straight into a gradient buffer); needs a workspace
 // of at least M x N floats.
+int tb_gemm_launch2(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                    long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
+                    int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
+
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
                    float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
+  return tb_gemm_launch2(A, lda, transA, B, ldb, transB, C, ldc, bias, nullptr, M, N, K, act, b_shift, b_period, ws,
+                         ws_bytes, stream, accumulate);
+}
+
+// bias2: optional second bias vector; the epilogue adds (bias + bias2), the two summed first
+int tb_gemm_launch2(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                    long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
+                    int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
   if (M <= 0 || N <= 0) return TB_OK;
   if (accumulate && (!ws || ws_bytes < (size_t)M * N * sizeof(float)))
     return tb_set_error(TB_ERR_WORKSPACE, "gemm: accumulate needs a workspace of M x N floats");
   if (K <= 0) return tb_set_error(TB_ERR_ARG, "gemm: K must be positive");
   GemmArgs a;
-  a.A = A; a.B = B; a.C = C; a.bias = bias;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.bias2 = bias2;
   a.M = M; a.N = N; a.K = K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.act = act;
@@ -407,7 +423,7 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_final_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, zstep, M, N, C, ldc, bias,
-                       act, accumulate);
+                       bias2, act, accumulate);
     TB_LAUNCH_CHECK("splitk_final_kernel");
   } else if (accumulate) {
     int blocks = (int)(((long)M * N + 255) / 256);

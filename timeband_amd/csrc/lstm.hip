@@ -44,6 +44,9 @@
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                    long ldc, const float* bias, int M, int N, int K, int act, int b_shift, int b_period,
                    float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
+int tb_gemm_launch2(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                    long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
+                    int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
 
 #ifdef TB_STAMPS
 // Diagnostic build only (tools/lstm_stamps.py): per-segment cycle sums of one workgroup's step loop.
@@ -1136,15 +1139,10 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: T*H too large (%d x %d)", T, H);
-  // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash
-  const float* bias = nullptr;
-  if (b_ih && b_hh) {
-    hipLaunchKernelGGL(bias_sum_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, b_ih, b_hh, c.bsum, 4 * H);
-    TB_LAUNCH_CHECK("bias_sum_kernel");
-    bias = c.bsum;
-  }
-  int rc = tb_gemm_launch(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, bias, B * T, 4 * H, in_dim, 0, 0, 1,
-                          nullptr, 0, s, 0);
+  // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash (the GEMM epilogue sums the two
+  // bias vectors first, then adds)
+  int rc = tb_gemm_launch2(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, b_ih, b_hh, B * T, 4 * H, in_dim, 0, 0, 1,
+                           nullptr, 0, s, 0);
   if (rc) return rc;
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   // algorithmic bytes of one layer forward: read x, write h, write the 5h stash
