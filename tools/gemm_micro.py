@@ -58,5 +58,8 @@ for (M, K, N) in cases:
             out["fwd_ms"] = ms / max(n, 1)
     fl = 2.0 * M * K * N
     fwd, bwd = out["fwd_ms"], out["bwd_ms"] / reps
+    if fwd <= 0 or bwd <= 0:      # one-column products go through the head kernels, not the GEMM
+        print(f"M={M} K={K} N={N}: not a GEMM launch (streaming head kernels)", flush=True)
+        continue
     print(f"M={M} K={K} N={N}: fwd {fwd:.3f} ms = {fl / fwd / 1e9:.1f} TF | bwd (dx+dW, {out['bwd_n']} launches) "
           f"{bwd:.3f} ms = {2 * fl / bwd / 1e9:.1f} TF", flush=True)
