@@ -947,10 +947,6 @@ __global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int
   if (db_hh) db_hh[i] = accumulate ? db_hh[i] + s : s;
 }
 
-__global__ void bias_sum_kernel(const float* b1, const float* b2, float* out, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = b1[i] + b2[i];
-}
 
 // ---- launch planning ---------------------------------------------------------------------
 struct Plan {
@@ -1055,7 +1051,7 @@ bool tile_fits_descriptor(const Plan& p, int T, int H) {
   return (long long)p.rows_per_cluster * T * 4 * H * 4 < 0x7FFFFFFFll;
 }
 
-// workspace carve: [hello | exchange (fwd: h ring, bwd: dh slabs) | bias sum | dbpart | gemm split-k slabs]
+// workspace carve: [hello | exchange (fwd: h ring, bwd: dh slabs) | dbpart | gemm split-k slabs]
 // Nothing in it has to be initialised: the kernels arm the exchange area themselves and the handshake
 // tags carry a per-launch epoch.
 unsigned long long next_epoch() {
@@ -1070,7 +1066,6 @@ unsigned long long next_epoch() {
 struct Carve {
   unsigned long long* hello; size_t hello_bytes;
   float* X; size_t x_bytes;
-  float* bsum;
   float* dbpart;
   float* gemm_ws; size_t gemm_ws_bytes;
 };
@@ -1083,7 +1078,6 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   // rings of 3 slots per cluster: forward rows x H floats (h_t all-gather), backward NCL x rows x H
   // (one partial of dh per producer, reduce-scatter)
   const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * p.rows_per_cluster * H * sizeof(float), 256) : 0;
-  const size_t bsum_bytes = tb_align_up((size_t)4 * H * sizeof(float), 256);
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   (void)in_dim;
   const size_t gemm_bytes = bwd ? tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
@@ -1091,8 +1085,6 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   off += hello_bytes;
   if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
   off += x_bytes;
-  if (c) c->bsum = reinterpret_cast<float*>(base + off);
-  off += bsum_bytes;
   if (c) c->dbpart = reinterpret_cast<float*>(base + off);
   off += dbpart_bytes;
   if (c) {

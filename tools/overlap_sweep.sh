@@ -2,7 +2,7 @@
 # bench line for each TB_OVERLAP mask (1 = GF under critic, 2 = GF2 under D backward, 4 = graph cut)
 set -o pipefail
 out=gpurun_out/${1:-ov}; mkdir -p $out
-for m in 7 0 1 2 4 3 5 6; do
+for m in 5 7 1 4 0; do
   TB_OVERLAP=$m timeout -k 10 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 > $out/ov$m.json || exit 1
   python - $m $out/ov$m.json <<'PY'
 import json,sys
