@@ -463,3 +463,78 @@ def test_adjust_scan_long_series_vs_oracle(dev, variant):
         np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13, equal_nan=True)
         if poison:
             assert np.isnan(got[350:, 9]).all() and np.isfinite(got[:350, 9]).all()
+
+
+def test_window_gather_vector_path_and_empty(dev):
+    """E % 4 == 0 takes the 16-byte copy path; zero windows is a no-op."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(10)
+    n, E, To, Tf = 500, 12, 7, 5
+    series = rng.uniform(-1, 1, (n, E)).astype(np.float32)
+    tcols = np.array([0, 3, 4, 11], np.int32)
+    enc_ref, dec_ref = O.windowing(series, tcols, To, Tf)
+    st, tc = T(series, dev), torch.tensor(tcols, dtype=torch.int32, device=dev)
+    enc, dec = ops.window_gather(st, tc, To, len(enc_ref), To, Tf)
+    assert np.array_equal(enc.cpu().numpy(), enc_ref) and np.array_equal(dec.cpu().numpy(), dec_ref)
+    enc, dec = ops.window_gather(st, tc, To + 3, 60, To, Tf, stride=2)
+    assert np.array_equal(enc.cpu().numpy(), enc_ref[3:123:2]) and np.array_equal(dec.cpu().numpy(), dec_ref[3:123:2])
+    enc, dec = ops.window_gather(st, tc, To, 0, To, Tf)
+    assert enc.shape == (0, To, E) and dec.shape == (0, Tf, 4)
+
+
+@pytest.mark.parametrize("Tf", [2, 16, 33, 64, 65, 130])
+def test_band_update_vs_oracle(dev, Tf):
+    """tb_band_update over several batches (history carried across them), with NaN predictions, for
+    horizons on both sides of the register-sort / wave-per-item switch; and with the denormalisation fused
+    into the gather against a separate tb_denormalize pass (must be identical)."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(Tf)
+    V, width = 37, 1.5
+    band = O.Band(Tf, V, width)
+    mk = lambda: [torch.zeros(Tf - 1, Tf, V, dtype=torch.float32, device=dev) for _ in range(2)]
+    hist, hist_n = mk(), mk()
+    cur = nh = 0
+    dmin = torch.tensor(rng.uniform(-5, 0, V), dtype=torch.float64, device=dev)
+    dmax = dmin + torch.tensor(rng.uniform(1, 9, V), dtype=torch.float64, device=dev)
+    for B in (3, 1, Tf + 4):
+        norm = rng.uniform(-1, 1, (B, Tf, V)).astype(np.float32)
+        norm[rng.random((B, Tf, V)) < 0.05] = np.nan
+        norm[:, :, 5] = np.nan if B == 1 else norm[:, :, 5]       # a variable without any valid forecast in one batch
+        tn = T(norm, dev)
+        pden = ops.denormalize(tn, dmin, dmax)
+        med, lo, up = ops.band_update(pden, hist[cur], nh, hist[cur ^ 1], width)
+        med2, lo2, up2 = ops.band_update(tn, hist_n[cur], nh, hist_n[cur ^ 1], width, dmin, dmax)
+        for a_, b_ in ((med, med2), (lo, lo2), (up, up2)):
+            assert torch.equal(torch.nan_to_num(a_, nan=1e30), torch.nan_to_num(b_, nan=1e30))
+        wmed, wlo, wup = band.predicts(pden.cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(med.cpu().numpy(), wmed, rtol=1e-12, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(lo.cpu().numpy(), wlo, rtol=1e-9, atol=1e-9, equal_nan=True)
+        np.testing.assert_allclose(up.cpu().numpy(), wup, rtol=1e-9, atol=1e-9, equal_nan=True)
+        cur ^= 1
+        nh = min(Tf - 1, nh + B)
+
+
+def test_lstm_single_step_single_row(dev):
+    """T = 1 (no recurrent product at all) and B = 1 (15 of a tile's 16 rows are padding)."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(77)
+    for (B, Tn, In, H) in ((1, 1, 5, 64), (1, 9, 8, 256), (17, 1, 8, 128)):
+        w_ih, w_hh, b_ih, b_hh = lstm_params(rng, In, H)
+        x = rng.uniform(-1, 1, (B, Tn, In)).astype(np.float32)
+        dy = rng.uniform(-1, 1, (B, Tn, H)).astype(np.float32)
+        f64 = lambda a: a.astype(np.float64)
+        y_ref, cache = O.lstm_layer_fwd(f64(x), f64(w_ih), f64(w_hh), f64(b_ih), f64(b_hh))
+        dx_ref, dwi_ref, dwh_ref, dbi_ref, _ = O.lstm_layer_bwd(f64(dy), cache)
+        ts = [T(a, dev).requires_grad_() for a in (x, w_ih, w_hh, b_ih, b_hh)]
+        y = ops.lstm_layer(*ts)
+        y.backward(T(dy, dev))
+        torch.cuda.synchronize()
+        ops.check_errors()
+        assert rel(y.detach().cpu().numpy(), y_ref) < 2e-5
+        assert rel(ts[0].grad.cpu().numpy(), dx_ref) < 1e-4
+        assert rel(ts[1].grad.cpu().numpy(), dwi_ref) < 1e-4
+        if Tn > 1:
+            assert rel(ts[2].grad.cpu().numpy(), dwh_ref) < 1e-4
+        else:
+            assert float(ts[2].grad.abs().max()) == 0.0          # h_{-1} = 0: no gradient reaches W_hh
+        assert rel(ts[3].grad.cpu().numpy(), dbi_ref) < 1e-4
