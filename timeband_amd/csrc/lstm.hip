@@ -226,6 +226,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int LPP = 16 * (US / 4) / 64;               // 16-byte loads per lane per producer (one 16-row tile)
   constexpr int NLD = NPP * LPP;                        // loads per lane per step
   constexpr int RS = MT * 16 * H;                       // floats per ring slot
+  // STAGE (one tile per cluster, H = 128 / 256): the pre-activations come in and y / the stash go out
+  // through LDS.  A lane finishes 2 units of one row, so its own loads and stores are 8 bytes at 16 rows x 4
+  // places per instruction (16 cache lines each; issuing one costs the wave ~90 cycles, 11 of them per step).
+  // Staged, the workgroup moves whole 128-byte runs: 2 loads + 3 stores of 16 bytes per lane and step, each
+  // instruction 8 full lines.  pbuf is double-buffered (step t+1 lands while step t is read); sbuf is
+  // written at the end of a step and flushed at the top of the next one, behind the barrier between them.
+  constexpr bool STAGE = MT == 1 && NCL > 1 && KS == 2 && US == 32;
+  constexpr int PROW = 4 * US + 8, SROW = 6 * US + 8;   // padded LDS rows: [4 gates][US], [4 gates, c, y][US]
   static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0 && (KS == 1 || KS == 2 || KS == 4), "bad config");
   static_assert(NCL == 1 || (NACT == 4 && (16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
 
@@ -236,6 +244,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   float* red = smem + MT * 16 * LDH;                   // [NUG][KS dst][KS src][64 lanes][4 gates][UPW]
   int* s_dead = reinterpret_cast<int*>(red + RED);
   int* s_word = s_dead + 1;
+  float* pbuf = red + RED + 4;                         // [2][16][PROW]   (STAGE)
+  float* sbuf = pbuf + 2 * 16 * PROW;                  // [16][SROW]      (STAGE)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 v = active ? ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = (active && !STAGE) ? ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < UPW; ++u) pre[mt][g][u] = v[u];
     }
@@ -299,6 +309,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     for (int u = 0; u < UPW; ++u) c[mt][u] = 0.f;
   }
   bool same_l2 = false;
+  if (STAGE) {   // step 0's pre-activations into pbuf[0] (the handshake's barriers publish them)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
+      *reinterpret_cast<f32x4*>(pbuf + r * PROW + g * US + c4 * 4) = ldg4<0>(rP, (long)r * rowP + g * H + j * US + c4 * 4);
+    }
+  }
   if (NCL > 1) {
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the arming stores (and the loads above) have landed
     const int hs = cluster_hello(a.hello + (size_t)cl * NCL, a.epoch, NCL, j, a.timeout_ticks, a.err, s_word);   // has barriers
@@ -310,12 +327,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 
   // the first pre-activations are complete before the loop (see the note at the prefetch wait below):
   // otherwise the loop-carried `pre` counts as pending and the gate math starts with a vmcnt(0)
+  if (!STAGE) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(pre[mt][g][u]));
+        for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(pre[mt][g][u]));
+  }
   STAMP_DECL;
 #ifdef TB_STAMPS
   stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
@@ -334,6 +353,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     for (int x = 0; x < MT; ++x) {
       const int mt = x;
       STAMP(0);
+      if (STAGE && t > 0) {
+        // y and the stash of step t-1, staged in sbuf before the barrier that ended that step
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg / 6, item = seg % 6;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + item * US + c4 * 4);
+          const long oy = (long)r * rowY + (long)(t - 1) * H + j * US + c4 * 4;
+          if (item == 5) stg4<0>(rY, oy, v);
+          else if (a.train) {
+            if (item == 4) stg4<0>(rC, oy, v);
+            else stg4<0>(rP, (long)r * rowP + (long)(t - 1) * 4 * H + item * H + j * US + c4 * 4, v);
+          }
+        }
+      }
       // (A) every consumer has read h_mt(t-2) (it published h_mt(t-1) after that, and our pull of
       // h_mt(t-1) is complete): re-arm this wave's part of that slot, which is written next at step t+1
       if (NCL > 1 && t >= 2) {
@@ -344,7 +377,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // + gate phase before the next hand-off load of this wave: loads return in order, so an HBM miss
       // issued just before a poll holds the poll and the pull behind it (measured: +2000 cycles per step)
       float nxt[4][UPW];
-      if (t + 1 < T && active) {
+      f32x4 pl[2];
+      if (STAGE && t + 1 < T) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
+          pl[i] = ldg4<0>(rP, (long)r * rowP + (long)(t + 1) * 4 * H + g * H + j * US + c4 * 4);
+        }
+      }
+      if (!STAGE && t + 1 < T && active) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
@@ -407,6 +448,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (active) {
         // (C) gate math, state update, h into LDS and the ring -- UPW consecutive units of one batch row per lane
         float z[4][UPW];
+        if (STAGE) {
+          const float* pb = pbuf + (t & 1) * 16 * PROW + col * PROW + (u0 - j * US);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const u32x2 w = *reinterpret_cast<const u32x2*>(pb + g * US);
+            pre[mt][g][0] = __uint_as_float(w[0]);
+            pre[mt][g][UPW - 1] = __uint_as_float(w[1]);
+          }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -467,7 +517,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           // of a wave complete in order: all but the 4 prefetch loads (and, with MT > 1, the NLD early pull
           // loads) issued after the re-arm.
           STAMP(5);
-          if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          if (STAGE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the 2 staged loads are all that follows the re-arm
+          else if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
           else if (NLD <= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
           else if (NLD <= 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -546,11 +597,27 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // has long completed: left alone, the compiler waits for them with vmcnt(0) at their first use in
       // the next phase's gate math -- behind the prefetch loads issued just before it (HBM latency, ~1200
       // cycles on the critical path of every step).
+      if (STAGE) {
+        if (t + 1 < T) {   // the next step's pre-activations into the other pbuf half
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+          for (int i = 0; i < 2; ++i) {
+            const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
+            *reinterpret_cast<f32x4*>(pbuf + ((t + 1) & 1) * 16 * PROW + r * PROW + g * US + c4 * 4) = pl[i];
+          }
+        }
+        float* sb = sbuf + col * SROW + (u0 - j * US);
 #pragma unroll
-        for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(nxt[g][u]));
-      if (active) {
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(sb + g * US) = (u32x2){__float_as_uint(st[g][0]), __float_as_uint(st[g][UPW - 1])};
+        *reinterpret_cast<u32x2*>(sb + 4 * US) = (u32x2){__float_as_uint(c[mt][0]), __float_as_uint(c[mt][UPW - 1])};
+        *reinterpret_cast<u32x2*>(sb + 5 * US) = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[UPW - 1])};
+      }
+      if (!STAGE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(nxt[g][u]));
+      }
+      if (active && !STAGE) {
         // (E) y for the next layer and the BPTT stash (activated gates over P in place, cell state): after
         // the pull, so that no HBM store sits in front of the hand-off loads
         f32x4 v;
@@ -578,6 +645,19 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       STAMP(9);
     }
     if (NCL > 1 && *s_dead) break;
+  }
+  if (STAGE && !*s_dead) {   // y and the stash of the last step (the loop ends with a barrier)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg / 6, item = seg % 6;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + item * US + c4 * 4);
+      const long oy = (long)r * rowY + (long)(T - 1) * H + j * US + c4 * 4;
+      if (item == 5) stg4<0>(rY, oy, v);
+      else if (a.train) {
+        if (item == 4) stg4<0>(rC, oy, v);
+        else stg4<0>(rP, (long)r * rowP + (long)(T - 1) * 4 * H + item * H + j * US + c4 * 4, v);
+      }
+    }
   }
   STAMP_FLUSH(0, cl, j);
 }
@@ -989,6 +1069,8 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   const int NUG = US / 16;
   const int HK = H < 32 ? 32 : H;
   p.lds_fwd = ((size_t)MT * 16 * (HK + 8) + (size_t)(KS > 1 ? NUG * KS * KS * 256 * (4 / KS) : 0)) * 4 + 16;
+  if (MT == 1 && p.NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8], sbuf [16][6*US+8]
+    p.lds_fwd += ((size_t)2 * 16 * (4 * US + 8) + (size_t)16 * (6 * US + 8)) * 4;
   p.lds_bwd = ((size_t)MT * 16 * (4 * US + 8) + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
   return true;
 }
