@@ -371,7 +371,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // h_mt(t-1) is complete): re-arm this wave's part of that slot, which is written next at step t+1
       if (NCL > 1 && t >= 2) {
         const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
-        stxn<UPW>(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
+        if (STAGE) {
+          // the member's whole slice as row-contiguous 16-byte pieces from the first 16*US/4 threads (8 full
+          // lines per instruction instead of 16 partial ones from every wave).  Any wave may re-arm any word
+          // of the slice: the store is acknowledged before that wave publishes (the guard below), hence
+          // before the barrier that ends this step, and the slot is written again only in the next step.
+          if (tid < 16 * (US / 4)) stx4(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(tid / (US / 4)) * H + j * US + (tid % (US / 4)) * 4, arm);
+        } else {
+          stxn<UPW>(same_l2, rR, (long)((t + 1) % 3) * RS + (long)(mt * 16 + col) * H + u0, arm);
+        }
       }
       // next step's pre-activations of this tile: independent of the recurrence.  Issued HERE, a whole MFMA
       // + gate phase before the next hand-off load of this wave: loads return in order, so an HBM miss
