@@ -8,7 +8,8 @@
  *   - tensors are dense, row-major, float32 unless typed otherwise;
  *   - `stream` is a hipStream_t (void*); work is enqueued, never synchronised;
  *   - the library allocates nothing on the device: callers pass workspaces sized by the
- *     matching *_workspace_bytes() query;
+ *     matching *_workspace_bytes() query, 256-byte aligned, contents arbitrary (nothing has to be
+ *     cleared); calls that may run at the same time (different streams) need different workspaces;
  *   - return value 0 = ok; otherwise tb_last_error() (host string, thread-local) says why.
  */
 #ifndef TIMEBAND_HIP_H

@@ -1213,6 +1213,7 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
   if (!x || !w_ih || !w_hh || !y || !gates || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
+  if (reinterpret_cast<uintptr_t>(ws) & 255) return tb_set_error(TB_ERR_ARG, "lstm_fwd: the workspace must be 256-byte aligned");
   if (train && !cstash) return tb_set_error(TB_ERR_ARG, "lstm_fwd: train needs a cell stash");
   Plan p;
   if (!make_plan(H, B, p, true))
@@ -1258,6 +1259,7 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   if (B <= 0 || T <= 0) return TB_OK;
   if (!dy || !x || !w_ih || !w_hh || !y || !gates || !cstash || !ws || !err)
     return tb_set_error(TB_ERR_ARG, "lstm_bwd: null pointer");
+  if (reinterpret_cast<uintptr_t>(ws) & 255) return tb_set_error(TB_ERR_ARG, "lstm_bwd: the workspace must be 256-byte aligned");
   Plan p;
   if (!make_plan(H, B, p))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d not supported (16,32,64,128,256,512)", H);
