@@ -57,7 +57,9 @@ def grads_close(module, want, tol, what):
     gmax = max(np.abs(v).max() for v in want.values())
     for k, p in module.named_parameters():
         err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
-        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        # per tensor; the floor (1 % of the tolerance times the largest gradient of the network) only keeps tensors
+        # whose own gradient is ~0 from being compared against their rounding noise
+        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax
         assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
 
 
@@ -67,7 +69,10 @@ MORE_LSTM_CASES = [
     (20, 40, 36, 512),      # clusters of 32, three puller waves, ring cycled 13 times
     (40, 70, 32, 256),      # clusters of 8, ragged third batch tile
     (100, 33, 64, 128),     # clusters of 4
-    (600, 9, 16, 128),      # more tiles than clusters: several batch tiles per cluster
+    (600, 9, 16, 128),      # 38 tiles on 64 clusters: one tile per cluster, ragged last tile
+    (1100, 20, 16, 128),    # forward with 2 batch tiles per cluster, ring re-armed for 18 steps
+    (2100, 12, 16, 128),    # forward with 4 batch tiles per cluster (BPTT: 4 tiles too)
+    (200, 20, 36, 512),     # hidden 512 forward with 2 tiles per cluster (k split over 4 waves, 32-member clusters)
     (1100, 5, 8, 256),      # 2 tiles per cluster AND a second launch
     (9, 130, 11, 16), (50, 64, 7, 32), (130, 48, 36, 64),   # single-workgroup layers, long sequences
 ]
@@ -93,6 +98,30 @@ def test_lstm_more_shapes(dev, B, Tn, In, H):
     for got, want, name in ((ts[0].grad, dx_ref, "dx"), (ts[1].grad, dwi_ref, "dw_ih"), (ts[2].grad, dwh_ref, "dw_hh"),
                             (ts[3].grad, dbi_ref, "db_ih"), (ts[4].grad, dbi_ref, "db_hh")):
         assert rel(got.cpu().numpy(), want) < 1e-3, name
+
+
+def test_two_clustered_launches_side_by_side(dev):
+    """Two hidden-512 forward launches with two batch tiles per cluster (the variant with the largest LDS
+    footprint, all 256 CUs) on two streams at once: both must be able to become fully resident (co-residency
+    rule of lstm.hip's make_plan) and give the bits of a launch that runs alone."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(12)
+    B, Tn, In, H = 200, 24, 36, 512
+    k = 1.0 / np.sqrt(H)
+    ps = [T(rng.uniform(-k, k, s), dev) for s in ((4 * H, In), (4 * H, H), (4 * H,), (4 * H,))]
+    xa, xb = T(rng.uniform(-1, 1, (B, Tn, In)), dev), T(rng.uniform(-1, 1, (B, Tn, In)), dev)
+    with torch.no_grad():
+        ya, yb = ops.lstm_layer(xa, *ps), ops.lstm_layer(xb, *ps)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        for _ in range(3):
+            with torch.cuda.stream(s1):
+                ya2 = ops.lstm_layer(xa, *ps)
+            with torch.cuda.stream(s2):
+                yb2 = ops.lstm_layer(xb, *ps)
+        torch.cuda.synchronize()
+    ops.check_errors()
+    assert torch.equal(ya, ya2) and torch.equal(yb, yb2)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -177,8 +206,8 @@ def test_cfg5_wide_cleaning_vs_oracle(dev):
     assert np.abs(got - outs).max() < 2e-4 * scale
     bands = bands_df.to_numpy()
     want_b = np.concatenate([lower, upper], axis=1)
-    if bands.shape == want_b.shape:     # same column order as the reference: lower block then upper block
-        assert np.abs(bands - want_b).max() < 5e-4 * scale
+    assert bands.shape == want_b.shape      # same column order as the reference: lower block then upper block
+    assert np.abs(bands - want_b).max() < 5e-4 * scale
 
 
 # ---------------------------------------------------------------------------------------------

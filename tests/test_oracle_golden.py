@@ -30,7 +30,7 @@ def relerr(a, b):
 
 
 def assert_grads_close(got, want, tol, what):
-    """Per tensor: max|got-want| <= tol*max|want| + 0.1*tol*(largest |grad| of the whole net).
+    """Per tensor: max|got-want| <= tol*max|want| + 0.01*tol*(largest |grad| of the whole net).
     The second term covers tensors whose value is the residue of a cancelling sum (e.g. the
     WGAN critic's bias gradient = mean over real minus mean over fake), where float32
     summation order alone moves the result by ~1e-3 of its own tiny magnitude."""
@@ -38,7 +38,7 @@ def assert_grads_close(got, want, tol, what):
     gmax = max(np.abs(v).max() for v in want.values())
     for k in want:
         err = np.abs(np.asarray(got[k], np.float64) - want[k]).max()
-        bound = tol * np.abs(want[k]).max() + 0.1 * tol * gmax
+        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax
         assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
 
 
@@ -97,10 +97,10 @@ def test_iteration_grads_and_steps(golden_dir, name):
     assert relerr(rec["critic.errD"], z["it0.critic.errD"]) < 1e-5
     assert_grads_close(rec["critic.grad.netD"], sub(z, "it0.critic.grad.netD"), 1e-3, "critic grad D")
     assert relerr(rec["dphase.errD"], z["it0.dphase.errD"]) < 1e-5
-    assert_grads_close(rec["dphase.grad.netD"], sub(z, "it0.dphase.grad.netD"), 1e-4, "dphase grad D")
+    assert_grads_close(rec["dphase.grad.netD"], sub(z, "it0.dphase.grad.netD"), 3e-4, "dphase grad D")
     assert_grads_close(rec["dphase.grad.netG"], sub(z, "it0.dphase.grad.netG"), 1e-3, "dphase grad G")
     assert relerr(rec["gphase.errG"], z["it0.gphase.errG"]) < 1e-5
-    assert_grads_close(rec["gphase.grad.netG"], sub(z, "it0.gphase.grad.netG"), 1e-4, "gphase grad G")
+    assert_grads_close(rec["gphase.grad.netG"], sub(z, "it0.gphase.grad.netG"), 3e-4, "gphase grad G")
     assert relerr(fake, z["it0.fake_y"]) < 1e-5
     # parameters after the steps: |update| is ~lr (Adam) or ~10 lr (fresh RMSprop) per element,
     # so compare the UPDATE, allowing sign flips only where the gradient is numerically zero

@@ -219,7 +219,9 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // group each take UPW = 4 / KS of a lane's 4 units (they swap the matching parts of their partial
   // sums through LDS), so gate math, publish and pull are spread over all the waves of the workgroup.
   constexpr int UPW = 4 / KS;
-  constexpr int RED = KS > 1 ? NUG * KS * KS * 256 * UPW : 0;   // floats of k-split scratch: [ug][dst][src][lane][4 gates][UPW]
+  // floats of k-split scratch: [ug][dst][src != dst][lane][4 gates][UPW] (a wave keeps its own part in registers, so
+  // there is no [dst][dst] slot: KS - 1 sources per destination, indexed (src - dst - 1) mod KS)
+  constexpr int RED = KS > 1 ? NUG * KS * (KS - 1) * 256 * UPW : 0;
   // exchange (NCL > 1): wave w pulls the slices of producers m = w, w + 4, ...
   constexpr int NPW = 4;
   constexpr int NPP = (NCL + NPW - 1) / NPW;            // producers per wave
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // h_{t-1} tile as split bf16 (hi, lo): [MT*16 rows][LDH], one ds_read_b128 per MFMA B operand
   unsigned short* hiL = reinterpret_cast<unsigned short*>(smem);
   unsigned short* loL = hiL + MT * 16 * LDH;
-  float* red = smem + MT * 16 * LDH;                   // [NUG][KS dst][KS src][64 lanes][4 gates][UPW]
+  float* red = smem + MT * 16 * LDH;                   // [NUG][KS dst][KS-1 src][64 lanes][4 gates][UPW]
   int* s_dead = reinterpret_cast<int*>(red + RED);
   int* s_word = s_dead + 1;
   float* pbuf = red + RED + 4;                         // [2][16][PROW]   (STAGE)
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
           for (int d = 0; d < KS; ++d) {
             if (d == kp) continue;
-            float* dst = red + (size_t)(((ug * KS + d) * KS + kp) * 64 + lane) * 4 * UPW;
+            float* dst = red + (size_t)(((ug * KS + d) * (KS - 1) + (kp - d - 1 + KS) % KS) * 64 + lane) * 4 * UPW;
             if (UPW == 2) {
               *reinterpret_cast<f32x4*>(dst) = (f32x4){acc[0][d * 2], acc[0][d * 2 + 1], acc[1][d * 2], acc[1][d * 2 + 1]};
               *reinterpret_cast<f32x4*>(dst + 4) = (f32x4){acc[2][d * 2], acc[2][d * 2 + 1], acc[3][d * 2], acc[3][d * 2 + 1]};
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
           for (int sr = 0; sr < KS; ++sr) {
             if (sr == kp) continue;
-            const float* src = red + (size_t)(((ug * KS + kp) * KS + sr) * 64 + lane) * 4 * UPW;
+            const float* src = red + (size_t)(((ug * KS + kp) * (KS - 1) + (sr - kp - 1 + KS) % KS) * 64 + lane) * 4 * UPW;
             if (UPW == 2) {
               const f32x4 p0 = *reinterpret_cast<const f32x4*>(src), p1 = *reinterpret_cast<const f32x4*>(src + 4);
               z[0][0] += p0[0]; z[0][1] += p0[1]; z[1][0] += p0[2]; z[1][1] += p0[3];
@@ -522,14 +524,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         if (NCL > 1 && t + 1 < T) {
           // the re-arm of (A) (and every older store of this wave) is acknowledged before new data enters
           // the ring: a consumer that sees h_t can no longer see an un-armed slot t+1.  Memory operations
-          // of a wave complete in order: all but the 4 prefetch loads (and, with MT > 1, the NLD early pull
-          // loads) issued after the re-arm.
+          // of a wave complete in order: all but the 4 prefetch loads (and, with MT > 1, the early pull loads)
+          // issued after the re-arm.
           STAMP(5);
-          if (STAGE) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // the 2 staged loads are all that follows the re-arm
-          else if (MT == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          else if (NLD <= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else if (NLD <= 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+          // The count is the MINIMUM any wave issues there: the wave that has this member among its producers
+          // skips that producer's LPP early pull loads (a larger count would not force the re-arm to complete).
+          constexpr int AFTER_REARM = STAGE ? 2 : (MT == 1 ? 4 : 4 + NLD - LPP);
+          static_assert(AFTER_REARM >= 0 && AFTER_REARM < 64, "vmcnt immediate");
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_REARM) : "memory");
           STAMP(6);
           stxn<UPW>(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
         }
@@ -1070,16 +1072,26 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   // launches always fit side by side.  BPTT at H=256 with two tiles needs 288 and is no faster than two
   // one-tile launches (6.0 vs 2 x 2.9 us/step), hence the cap of 1 there.
   const int mt_cap = fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4));
-  while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters) MT *= 2;
+  const int NUG = US / 16;
+  const int HK = H < 32 ? 32 : H;
+  const int NCL = p.NCL;
+  auto lds_f = [=](int mt) {
+    size_t b = ((size_t)mt * 16 * (HK + 8) + (size_t)(KS > 1 ? NUG * KS * (KS - 1) * 256 * (4 / KS) : 0)) * 4 + 16;
+    if (mt == 1 && NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8], sbuf [16][6*US+8]
+      b += ((size_t)2 * 16 * (4 * US + 8) + (size_t)16 * (6 * US + 8)) * 4;
+    return b;
+  };
+  auto lds_b = [=](int mt) { return ((size_t)mt * 16 * (4 * US + 8) + (size_t)mt * 16 * (H + 4) + 4096) * 4 + 16; };
+  // ... and within half a CU's LDS (80 KiB): a clustered variant leaves room for a second clustered workgroup
+  constexpr size_t kLdsHalf = 80 * 1024;
+  auto fits = [=](int mt) { return NCL == 1 || (fwd ? lds_f(mt) : lds_b(mt)) <= kLdsHalf; };
+  while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters && fits(2 * MT)) MT *= 2;
   p.MT = MT;
   p.rows_per_cluster = 16 * MT;
   p.clusters_per_launch = max_clusters;
-  const int NUG = US / 16;
-  const int HK = H < 32 ? 32 : H;
-  p.lds_fwd = ((size_t)MT * 16 * (HK + 8) + (size_t)(KS > 1 ? NUG * KS * KS * 256 * (4 / KS) : 0)) * 4 + 16;
-  if (MT == 1 && p.NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8], sbuf [16][6*US+8]
-    p.lds_fwd += ((size_t)2 * 16 * (4 * US + 8) + (size_t)16 * (6 * US + 8)) * 4;
-  p.lds_bwd = ((size_t)MT * 16 * (4 * US + 8) + (size_t)MT * 16 * (H + 4) + 4096) * 4 + 16;
+  p.lds_fwd = lds_f(MT);
+  p.lds_bwd = lds_b(MT);
+  if (!fits(MT)) return false;
   return true;
 }
 
@@ -1187,29 +1199,9 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
 
 }  // namespace
 
-extern "C" {
-
-#ifdef TB_STAMPS
-int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
-  return tb_check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(tb_stamps), sizeof(unsigned long long) * 2 * 4 * 12), "stamps");
-}
-#endif
-
-size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
-  (void)T;
-  Plan p;
-  if (!make_plan(H, B, p, backward == 0)) return 0;
-  return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
-}
-
-int tb_lstm_supported(int H) {
-  Plan p;
-  return make_plan(H, 16, p) ? 1 : 0;
-}
-
-int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
-                float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
-                void* ws, size_t ws_bytes, int* err, void* stream) {
+static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                         float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                         void* ws, size_t ws_bytes, int* err, void* stream, bool prof) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
   if (!x || !w_ih || !w_hh || !y || !gates || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
@@ -1243,12 +1235,39 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
     a.train = train;
     a.timeout_ticks = kTimeoutTicks;
     // timed region = the recurrent kernel(s): the event goes in after the fill that arms the exchange area
-    if (c0 == 0) tb_prof_begin(TB_K_LSTM_FWD, s, 4.0 * B * T * (train ? (in_dim + 6.0 * H) : (in_dim + 1.0 * H)));
+    if (prof && c0 == 0) tb_prof_begin(TB_K_LSTM_FWD, s, 4.0 * B * T * (train ? (in_dim + 6.0 * H) : (in_dim + 1.0 * H)));
     rc = launch_fwd(p, a, ncl * p.NCL, s);
     if (rc) return rc;
   }
-  tb_prof_end(TB_K_LSTM_FWD, s);
+  if (prof) tb_prof_end(TB_K_LSTM_FWD, s);
   return TB_OK;
+}
+
+
+extern "C" {
+
+#ifdef TB_STAMPS
+int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
+  return tb_check_hip(hipMemcpyFromSymbol(out, HIP_SYMBOL(tb_stamps), sizeof(unsigned long long) * 2 * 4 * 12), "stamps");
+}
+#endif
+
+size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
+  (void)T;
+  Plan p;
+  if (!make_plan(H, B, p, backward == 0)) return 0;
+  return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
+}
+
+int tb_lstm_supported(int H) {
+  Plan p;
+  return make_plan(H, 16, p) ? 1 : 0;
+}
+
+int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                void* ws, size_t ws_bytes, int* err, void* stream) {
+  return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, y, gates, cstash, B, T, in_dim, H, train, ws, ws_bytes, err, stream, true);
 }
 
 int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
