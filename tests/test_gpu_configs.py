@@ -59,7 +59,7 @@ def grads_close(module, want, tol, what):
         err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
         # per tensor; the floor (1 % of the tolerance times the largest gradient of the network) only keeps tensors
         # whose own gradient is ~0 from being compared against their rounding noise
-        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax
+        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax + 2e-7    # 2e-7: fp32 rounding of the reference's own cancelling O(1) sums (WGAN bias gradients)
         assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
 
 

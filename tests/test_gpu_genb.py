@@ -28,7 +28,7 @@ def grads_close(module, want, tol, what):
     gmax = max(np.abs(v).max() for v in want.values())
     for k, p in module.named_parameters():
         err = np.abs(p.grad.detach().cpu().numpy().astype(np.float64) - want[k]).max()
-        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax
+        bound = tol * np.abs(want[k]).max() + 0.01 * tol * gmax + 2e-7    # 2e-7: fp32 rounding of the reference's own cancelling O(1) sums (WGAN bias gradients)
         assert err <= bound, f"{what}:{k} err {err:.3e} > {bound:.3e}"
 
 
