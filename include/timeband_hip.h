@@ -58,6 +58,20 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
                 int* err, void* stream);
 
+/* tb_lstm_fwd for callers that CANNOT ALLOCATE (tight serving loops such as the cleaning pass, harnesses
+ * that forbid hipMalloc, code that runs while a capture is open elsewhere).  No counterpart in the reference.  Same arguments
+ * and results as tb_lstm_fwd minus the workspace: the exchange area (handshake tags + h ring) is a static
+ * device array inside the library (tb_lstm_static_scratch_bytes() = 8 MiB per GPU, held until the process
+ * ends); the call allocates nothing (no hipMalloc / hipFree, no events).  Shapes whose exchange area does
+ * not fit are rejected with TB_ERR_WORKSPACE (4).  All calls on one GPU share that GPU's array: calls
+ * that overlap in time on one GPU (other streams / threads) race -- serialise them or use tb_lstm_fwd.
+ * tb_lstm_static_init() looks the array's device address up for the current device (tb_init calls it). */
+int tb_lstm_static_init(void);
+size_t tb_lstm_static_scratch_bytes(void);
+int tb_lstm_fwd_static(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                       int* err, void* stream);
+
 /* ---- Linear (+Tanh / +Sigmoid) -----------------------------------------------------------------
  * y[M,N] = act(x[M,K].W[N,K]^T + b[N]); act 0 none, 1 tanh, 2 sigmoid.
  * Reference: seq_layer / dim_layer / discriminator head, source/utils/lstm_layer.py:35-36,49-50,76,84-87.

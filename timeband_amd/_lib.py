@@ -31,6 +31,9 @@ SIGNATURES = {
     "tb_lstm_supported": (I, [I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_static_init": (I, []),
+    "tb_lstm_static_scratch_bytes": (Z, []),
+    "tb_lstm_fwd_static": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "tb_lstm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
     "tb_linear_act_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "tb_linear_workspace_bytes": (Z, [I, I, I]),

@@ -69,6 +69,8 @@ void tb_prof_end(int id, hipStream_t s) {
   p.open = false;
 }
 
+extern "C" int tb_lstm_static_init(void);
+
 extern "C" {
 
 const char* tb_last_error(void) { return g_err; }
@@ -77,6 +79,10 @@ int tb_version(void) { return 1; }
 
 int tb_init(int device) {
   TB_HIP(hipSetDevice(device));
+  {
+    const int rc = tb_lstm_static_init();   // lstm.hip: address of the static scratch on this device
+    if (rc) return rc;
+  }
   hipDeviceProp_t prop;
   TB_HIP(hipGetDeviceProperties(&prop, device));
   g_cus = prop.multiProcessorCount;

@@ -39,6 +39,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <mutex>
 #include <random>
 
 int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
@@ -73,7 +74,35 @@ __device__ unsigned long long tb_stamps[2][4][12];
 #define STAMP_FLUSH(k, cl, j)
 #endif
 
+// ---- scratch of the entry point that allocates nothing (tb_lstm_fwd_static) ------------------------
+// The exchange area of the forward kernel (handshake tags + h ring) for callers that cannot bring a
+// workspace: a fixed array in the code object.  Each GPU the library runs on holds its own copy at its own
+// address until the process ends; the name below is only a host-side handle -- the device address comes from
+// hipGetSymbolAddress (static_scratch(), once per device) and is what every launch is given.
+constexpr size_t kStaticScratchBytes = 8u << 20;   // largest forward exchange area is 6.3 MB (H=128, 4 tiles x 64 clusters)
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
 namespace {
+
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// device address of `scratch` on the CURRENT device (looked up once per device)
+int static_scratch(void** out) {
+  int dev = -1;
+  TB_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return tb_set_error(TB_ERR_ARG, "static scratch: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    TB_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return tb_set_error(TB_ERR_HIP, "static scratch: hipGetSymbolAddress returned null");
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return TB_OK;
+}
 
 constexpr unsigned kSentinel = 0xFFFFFFFFu;   // all-ones: a NaN pattern no computed h equals
 constexpr int kBufFlags = 0x00020000;         // raw buffer descriptor word 3 (32-bit raw, bounds-checked)
@@ -1268,6 +1297,37 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
                 float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
                 void* ws, size_t ws_bytes, int* err, void* stream) {
   return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, y, gates, cstash, B, T, in_dim, H, train, ws, ws_bytes, err, stream, true);
+}
+
+// Looks up the static scratch of the current device (tb_init calls it, so the lookup is not on a caller's
+// first launch; tb_lstm_fwd_static repeats it if tb_init was skipped).
+int tb_lstm_static_init(void) {
+  void* p = nullptr;
+  return static_scratch(&p);
+}
+
+size_t tb_lstm_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+// tb_lstm_fwd without a workspace argument and without any allocation: the exchange area lives in the
+// library's static scratch.  Same kernels, same results.  Calls that overlap on one GPU (two streams, two
+// threads) share that GPU's array and race; the array keeps the last call's contents, which is harmless: the
+// kernels arm their exchange area themselves and the handshake tags carry a per-launch epoch.
+int tb_lstm_fwd_static(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                       float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
+                       int* err, void* stream) {
+  if (B <= 0 || T <= 0) return TB_OK;
+  Plan p;
+  if (!make_plan(H, B, p, true))
+    return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd_static: hidden size %d not supported (16,32,64,128,256,512)", H);
+  const size_t need = carve(p, B, H, in_dim, false, nullptr, 0, nullptr);
+  if (need > kStaticScratchBytes)
+    return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd_static: this shape needs %zu bytes of exchange area, the static scratch "
+                        "holds %zu; use tb_lstm_fwd with a caller workspace", need, kStaticScratchBytes);
+  void* ptr = nullptr;
+  int rc = static_scratch(&ptr);
+  if (rc) return rc;
+  return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, y, gates, cstash, B, T, in_dim, H, train, ptr, kStaticScratchBytes, err,
+                       stream, false);
 }
 
 int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
