@@ -33,6 +33,8 @@ CONFIGS = {
     # name: V, time features, To, Tf, H, L, batch per GPU, series length
     "cfg1": dict(V=7, NT=4, To=48, Tf=48, H=64, L=1, B=1024, N=20000),
     "cfg2": dict(V=32, NT=4, To=128, Tf=128, H=256, L=1, B=512, N=100000),
+    # BASELINE.json configs[3], long context (not the headline; the critic batch is forecast_len = 1024 windows)
+    "cfg4": dict(V=32, NT=4, To=1024, Tf=1024, H=512, L=2, B=64, N=12000),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -115,17 +117,34 @@ def main():
                          "reference's two identical forwards (see TIMEBANDTrainer.share_gpass)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly with --gpus N: launch the N ranks (one process per GPU) as children BEFORE anything
+        # here touches the GPU, and pass their exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == args.gpus
 
     cfg = CONFIGS[args.config]
     ds, trainset, trainer = build(cfg, device)
@@ -137,14 +156,23 @@ def main():
     nbatches = len(trainset) // (B * world)
     if nbatches < 1:
         raise SystemExit("series too short for this batch / world size")
+    from timeband_amd.dataset import WindowSet
+    # the product's own sharding: global batches of B * world windows, this rank's contiguous slice of each
+    # (weak scaling: B windows per GPU); whole batches only, cycled
+    loader = WindowSet(ds, trainset.w0, nbatches * B * world).loader(B * world, rank, world)
+    state = {"it": iter(loader), "seen": 0}
 
     def step(i):
-        g0 = (i % nbatches) * B * world + rank * B      # this rank's contiguous shard of global batch i
-        batch = trainset.gather(g0, B)
-        fake = trainer.iteration(batch["encoded"], batch["decoded"], training=True)
+        if state["seen"] == nbatches:
+            state["it"], state["seen"] = iter(loader), 0
+            trainer.post.reset()
+        batch = next(state["it"])
+        state["seen"] += 1
+        part = batch.get("part")
+        fake = trainer.iteration(batch["encoded"], batch["decoded"], training=True,
+                                 n_global=None if part is None else part[1])
         if args.full:
-            trainer.post.idx = g0
-            trainer.metric.update(*trainer.post.step(fake)[:3])
+            trainer.metric.update(*trainer.post.step(fake, part)[:3])
 
     def barrier():
         if world > 1:
@@ -201,7 +229,8 @@ def main():
         traffic, traffic_src = pmc_traffic(f"{dom}_kernel") if args.config == "cfg2" else (None, None)
         out = {
             "metric": "G+D training windows/sec", "value": round(value, 2), "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 0, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: LSTM-GAN G+D iteration (critic=1 + D phase + G phase), "

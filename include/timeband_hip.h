@@ -148,11 +148,24 @@ int tb_denormalize(const float* x, long n, int V, const double* dmin, const doub
 int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
                    const double* dmin, const double* dmax, double band_width, double* med, double* sd, double* lower,
                    double* upper, void* stream);
+/* tb_band_update restricted to the first rows_out <= B+Tf-1 rows, with the std smear over the last Tf rows
+ * (source/trainer.py:280-282) optional (it needs every row).  No counterpart in the single-device reference:
+ * a data-parallel rank that is not the last of its global batch computes its own B rows unsmeared -- the
+ * overhang belongs to its right neighbour.  hist_out may be NULL here. */
+int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
+                        const double* dmin, const double* dmax, double band_width, double* med, double* sd,
+                        double* lower, double* upper, int rows_out, int smear, void* stream);
 int tb_adjust_scan(int variant, const double* seed, const double* reals, const double* preds, const int* masks,
                    const double* lower, const double* upper, int n, int V, double missing_gamma,
                    double anomaly_gamma, double* target, void* stream);
 int tb_metrics(const double* tru, const double* pred, const int* mask, long n, double* out, double* running,
                void* stream);
+
+/* tb_metrics in two stages (source/metric.py:30-73): sums[5] = [sum sq err, #unmasked, sum ne, sum |ne|,
+ * #unmasked non-zero] of one batch's rows -- additive over data-parallel ranks, the scores are not -- and
+ * the scores of k batches from their (summed) sums[k][5]: out[k][3] (nullable), running[3] += (nullable). */
+int tb_metric_sums(const double* tru, const double* pred, const int* mask, long n, double* sums, void* stream);
+int tb_metric_finish(const double* sums, int k, double* out, double* running, void* stream);
 
 #ifdef __cplusplus
 }

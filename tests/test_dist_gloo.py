@@ -103,8 +103,10 @@ def _worker_replicated(rank, world, port, out):
     x = torch.arange(12.0).reshape(6, 2)
     cx, cy, shared = TIMEBANDTrainer._shard_critic(x, x)         # 6 windows / 2 ranks -> 3 each
     ok = shared and torch.equal(cx, x[rank * 3:(rank + 1) * 3])
-    cx2, _, shared2 = TIMEBANDTrainer._shard_critic(x[:5], x[:5])  # 5 does not divide -> replicated
-    ok = ok and (not shared2) and cx2.shape[0] == 5
+    cx2, _, shared2 = TIMEBANDTrainer._shard_critic(x[:5], x[:5])  # 5 windows / 2 ranks -> ragged slices 2 + 3
+    ok = ok and shared2 and cx2.shape[0] == (2 if rank == 0 else 3)
+    cx3, _, shared3 = TIMEBANDTrainer._shard_critic(x[:1], x[:1])  # fewer windows than ranks -> replicated
+    ok = ok and (not shared3) and cx3.shape[0] == 1
     if rank == 0:
         np.save(out, np.array([a, b, c, int(ok)]))
     dist.barrier()

@@ -1,0 +1,261 @@
+"""Data-parallel host logic of the PRODUCT on CPU (gloo, world_size 2): the code that decides who owns
+which windows and rows and what travels between ranks -- timeband_amd.dp (shard, count_scale, ring_shift,
+row carry, all-gather, GradReducer), WindowSet.loader(batch, rank, world), BandAdjust's halo / carry /
+short-slice paths, TIMEBANDMetric's two-stage scores, TIMEBANDTrainer._shard_critic, FlatParams' buckets.
+
+The HIP kernels need a GPU, so the four kernel wrappers the host logic calls (ops.window_gather,
+ops.band_update, ops.adjust_scan, ops.metric_sums / metric_finish) are replaced IN THE TEST by the numpy
+oracle; everything else is the product's code.  The check: two ranks, each running the generator (oracle)
+on its own slice of every global batch, produce -- across every shard boundary -- the cleaned series and the
+bands the REFERENCE produced in one process (tests/golden/pipeline.npz, clean.outputs / clean.bands), and
+the scores the single-process oracle computes.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _install_oracle_kernels(O, series):
+    """Numpy stand-ins for the kernel wrappers (test only)."""
+    from timeband_amd import ops
+
+    def window_gather(series_t, tcols, first, nwin, To, Tf, stride=1, starts=None):
+        s = series_t.numpy()
+        tc = tcols.numpy()
+        idx = [first + w * stride for w in range(nwin)]
+        enc = np.stack([s[i - To:i] for i in idx]) if nwin else np.zeros((0, To, s.shape[1]), np.float32)
+        dec = np.stack([s[i:i + Tf][:, tc] for i in idx]) if nwin else np.zeros((0, Tf, len(tc)), np.float32)
+        return torch.from_numpy(enc.astype(np.float32)), torch.from_numpy(dec.astype(np.float32))
+
+    def band_update(pden, hist_in, nhist, hist_out, band_width, dmin=None, dmax=None, rows_out=None, smear=True):
+        B, Tf, V = pden.shape
+        den = lambda t: O.denormalize(t.numpy(), dmin.numpy(), dmax.numpy()).astype(np.float64)
+        band = O.Band(Tf, V, band_width)
+        if nhist > 0:
+            band.predicts(den(hist_in[Tf - 1 - nhist:]))      # the state only depends on the last Tf-1 windows
+        med, lo, up = band.predicts(den(pden))
+        R = B + Tf - 1 if rows_out is None else rows_out
+        # the smear only touches the Tf-1 overhang rows: an unsmeared part never includes them
+        assert smear or R <= B
+        if hist_out is not None:
+            allw = torch.cat([hist_in, pden])
+            hist_out.copy_(allw[-(Tf - 1):])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:R]))
+        return t(med), t(lo), t(up)
+
+    def adjust_scan(variant, seed, reals, preds, masks, lower, upper, a, b):
+        out = np.concatenate([seed.numpy()[None], reals.numpy()]).copy()
+        tgt = O.adjust(variant, out, preds.numpy(), masks.numpy(), lower.numpy(), upper.numpy(), a, b)
+        return torch.from_numpy(np.ascontiguousarray(tgt))
+
+    def metric_sums(reals, preds, masks):
+        t, p, m = reals.numpy(), preds.numpy(), masks.numpy()
+        sel = m == 0
+        t, p = t[sel], p[sel]
+        nz = t != 0
+        ne = (t[nz] - p[nz]) / (1e-7 + t[nz])
+        return torch.tensor([((t - p) ** 2).sum(), float(sel.sum()), ne.sum(), np.abs(ne).sum(), float(nz.sum())],
+                            dtype=torch.float64)
+
+    def metric_finish(sums, running=None):
+        s = sums.numpy()
+        out = np.stack([s[:, 2] / s[:, 4], s[:, 3] / s[:, 4], np.sqrt(s[:, 0] / s[:, 1])], 1)
+        if running is not None:
+            running += torch.from_numpy(out.sum(0))
+        return torch.from_numpy(out)
+
+    ops.window_gather, ops.band_update, ops.adjust_scan = window_gather, band_update, adjust_scan
+    ops.metric_sums, ops.metric_finish = metric_sums, metric_finish
+
+
+def _cpu_dataset(s, B, To, Tf):
+    """TIMEBANDDataset's device state with CPU tensors (the product refuses a CPU device on purpose)."""
+    from timeband_amd.dataset import TIMEBANDDataset
+    ds = TIMEBANDDataset.__new__(TIMEBANDDataset)
+    ds.observed_len, ds.forecast_len, ds.stride, ds.batch_size = To, Tf, 1, B
+    ds.data_length, ds.encode_dim, ds.decode_dim = s.data_length, s.norm.shape[1], len(s.target_cols)
+    ds.series_dev = torch.from_numpy(s.norm.astype(np.float32))
+    ds.tcols_dev = torch.tensor(s.target_cols, dtype=torch.int32)
+    ds.forecast_dev = torch.from_numpy(s.forecast.copy())
+    ds.observed_dev = torch.from_numpy(s.observed.copy())
+    ds.missing_dev = torch.from_numpy(s.missing.astype(np.int32))
+    ds.dmin_dev, ds.dmax_dev = torch.from_numpy(s.decode_min.copy()), torch.from_numpy(s.decode_max.copy())
+    ds.sliding_step = 0
+
+    class _L:
+        def info(self, *a, **k):
+            pass
+    ds.logger = _L()
+    return ds
+
+
+def _worker(rank, world, port, golden, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import timeband_oracle as O
+    from timeband_amd import dp, synthetic
+    from timeband_amd.metric import TIMEBANDMetric
+    from timeband_amd.postprocess import BandAdjust
+    z = np.load(golden)
+    V, To, Tf, H, L, B, N = (int(v) for v in z["meta"])
+    values = synthetic.make_series(N, V, seed=31)
+    tfeat = synthetic.time_features(N + Tf)
+    s = O.SeriesData(values, tfeat, To, Tf, split_rate=0.8)
+    _install_oracle_kernels(O, s)
+    ds = _cpu_dataset(s, B, To, Tf)
+    pG = {k[len("ep0.train.netG."):]: z[k] for k in z.files if k.startswith("ep0.train.netG.")}
+
+    full = ds.prepare_dataset(split=False)
+    assert len(full) == int(z["full_len"])
+    post = BandAdjust(ds, "cleaner", 1.0, 0.2, 0.3, keep_outputs=True)
+    metric = TIMEBANDMetric(dict(device="cpu"))
+    stamp = np.full(ds.data_length, -1, np.int64)       # step at which this rank last wrote a row
+    seen = []
+    for step, data in enumerate(full.loader(B, rank, world)):
+        lo, n, repl = data["part"]
+        assert data["encoded"].shape[0] == (n if repl else dp.shard(n)[1] - dp.shard(n)[0])
+        fake, _ = O.generator_fwd(pG, data["encoded"].numpy(), L)
+        idx0 = post.idx
+        reals, preds, masks, lower, upper, target = post.step(torch.from_numpy(fake[:, :Tf].astype(np.float32)), data["part"])
+        first = To + idx0 + (lo if target.shape[0] < n + Tf - 1 else 0)
+        stamp[first:first + target.shape[0]] = step
+        seen.append((lo, n, repl, target.shape[0]))
+        metric.update(reals, preds, masks)
+    scores = [metric.nme, metric.nmae, metric.rmse]          # all-reduces the pending sums
+    np.savez(f"{out}.{rank}.npz", outputs=post.outputs.numpy(), lower=post.lower_bands.numpy(),
+             upper=post.upper_bands.numpy(), stamp=stamp, scores=np.array(scores), parts=np.array(seen, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_band_adjust_across_shard_boundaries(tmp_path, golden_dir):
+    golden = os.path.join(golden_dir, "pipeline.npz")
+    out = str(tmp_path / "dp.npz")
+    mp.spawn(_worker, args=(2, _free_port(), golden, out), nprocs=2, join=True)
+    rs = [np.load(f"{out}.{k}.npz") for k in range(2)]
+    z = np.load(golden)
+    V, To, Tf, H, L, B, N = (int(v) for v in z["meta"])
+    want_o, want_b = z["clean.outputs"], z["clean.bands"]
+    n = want_o.shape[0]
+    # a row belongs to whoever wrote it LAST (the overhang rows of a batch are rewritten by the next batch's first
+    # rank, exactly as the reference's next batch overwrites them, cleaner.py:97-99)
+    stamps = np.stack([r["stamp"] for r in rs])
+    who = stamps.argmax(0)
+    assert (stamps.max(0)[To:n] >= 0).all()
+    pick = lambda key: np.where((who == 0)[:, None], rs[0][key], rs[1][key])
+    # the first To rows are `observed` (never predicted)
+    np.testing.assert_allclose(pick("outputs")[To:n], want_o[To:], rtol=2e-4, atol=2e-5)
+    got_b = np.concatenate([pick("lower")[:n], pick("upper")[:n]], axis=1)
+    np.testing.assert_allclose(got_b[To:], want_b[To:], rtol=2e-4, atol=2e-4)
+    r = rs[0]
+    np.testing.assert_allclose(rs[0]["scores"], rs[1]["scores"], rtol=1e-12)
+    # 12 full batches went through the halo path (slices of 16 >= Tf-1), the 13-window tail through the all-gather
+    parts = r["parts"]
+    assert len(parts) == 13 and parts[-1][1] == 13 and parts[0][1] == 32
+    # scores: the single-process oracle over the same pass
+    sys.path.insert(0, ROOT)
+    from oracle import timeband_oracle as O
+    from timeband_amd import synthetic
+    s = O.SeriesData(synthetic.make_series(N, V, seed=31), synthetic.time_features(N + Tf), To, Tf, 0.8)
+    pG = {k[len("ep0.train.netG."):]: z[k] for k in z.files if k.startswith("ep0.train.netG.")}
+    enc, _ = O.windowing(s.norm, s.target_cols, To, Tf)
+    pp = O.PostProcess(s, "cleaner", 1.0, 0.2, 0.3)
+    sums = np.zeros(3)
+    for s0 in range(0, len(enc), B):
+        fake, _ = O.generator_fwd(pG, enc[s0:s0 + B], L)
+        reals, preds, masks, *_ = pp.step(fake[:, :Tf])
+        sums += np.array(O.metrics(reals, preds, masks))
+    np.testing.assert_allclose(r["scores"], sums, rtol=1e-9)
+
+
+def _worker_units(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from timeband_amd import dp, ops
+    from timeband_amd.optim import FlatParams
+    from timeband_amd.trainer import TIMEBANDTrainer
+    from timeband_amd.utils.lstm_layer import LSTMGenerator
+    ok = []
+    # shards: contiguous, cover everything, sizes differ by at most one
+    for n in (2, 7, 32, 33):
+        b = [dp.shard(n, r, world) for r in range(world)]
+        ok.append(b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1)))
+    # global counts: equal slices by default, explicit counts for ragged ones, local inside replicated()
+    ok.append(dp.count_scale(10) == 20.0 and ops._world() == 2)
+    with dp.batch_counts(3, 7):
+        ok.append(dp.count_scale(3 * 5) == 35.0)
+    with dp.replicated():
+        ok.append(dp.count_scale(10) == 10.0 and ops._world() == 1 and not dp.active())
+    ok.append(dp.active())
+    # critic slices
+    x = torch.arange(14.0).reshape(7, 2)
+    cx, cy, shared = TIMEBANDTrainer._shard_critic(x, x)
+    lo, hi = dp.shard(7)
+    ok.append(shared and torch.equal(cx, x[lo:hi]))
+    _, _, shared1 = TIMEBANDTrainer._shard_critic(x[:1], x[:1])
+    ok.append(not shared1)
+    # primitives
+    t = torch.full((3,), float(rank + 1))
+    h = dp.all_reduce_async(t)
+    h.wait()
+    ok.append(torch.equal(t, torch.full((3,), 3.0)))
+    recv = torch.empty(2)
+    dp.ring_shift(torch.full((2,), float(rank)), recv)
+    ok.append(torch.equal(recv, torch.full((2,), float((rank - 1) % world))))
+    g = dp.all_gather_cat(torch.full((rank + 1, 2), float(rank)))
+    ok.append(g.shape == (3, 2) and g[0, 0] == 0 and g[2, 1] == 1)
+    # buckets of the generator's flat buffer: backward-completion order, contiguous, covering
+    netG = LSTMGenerator(36, 32, 128, 128, 256, 1)
+    fake_flat = type("F", (), {})()
+    buckets = FlatParams._make_buckets(fake_flat, netG)
+    names = [b["names"] for b in buckets]
+    ok.append(names == [["dim_layer", "seq_layer", "lstm2"], ["lstm1"], ["lstm0"]])
+    total = sum(p.numel() for p in netG.parameters())
+    ok.append(buckets[0]["hi"] == total and buckets[-1]["lo"] == 0
+              and all(buckets[i]["lo"] == buckets[i + 1]["hi"] for i in range(len(buckets) - 1)))
+    # reducer: buckets fire when their last parameter reports; finish() sums everything exactly once
+    fake_flat.buckets = buckets
+    fake_flat.grad = torch.full((total,), float(rank + 1))
+    for p in netG.parameters():
+        p._tb_flat = fake_flat
+    red = dp.GradReducer(fake_flat)
+    red.arm()
+    slots = [object()] * 4
+    ops.grads_enqueued(slots[:2], list(netG.dim_layer.parameters()))
+    ops.grads_enqueued(slots[:2], list(netG.seq_layer.parameters()))
+    ok.append(red.fired == [False, False, False])
+    ops.grads_enqueued(slots, list(netG.lstm2.parameters()))
+    ok.append(red.fired == [True, False, False])
+    ops.grads_enqueued(slots, list(netG.lstm1.parameters()))
+    ok.append(red.fired == [True, True, False])
+    red.finish()                                  # lstm0 never reported: finish() reduces it
+    ok.append(torch.equal(fake_flat.grad, torch.full((total,), 3.0)) and not ops._REDUCERS)
+    if rank == 0:
+        np.save(out, np.array(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp2_sharding_counts_primitives_buckets(tmp_path):
+    out = str(tmp_path / "u.npy")
+    mp.spawn(_worker_units, args=(2, _free_port(), out), nprocs=2, join=True)
+    ok = np.load(out)
+    assert ok.all(), ok

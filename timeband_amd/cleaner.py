@@ -24,7 +24,7 @@ class TIMEBANDCleaner:
         with torch.no_grad():
             for data in dataset:
                 fake_y = netG(data["encoded"].to(dev))[:, : self.forecast_len]
-                post.step(fake_y)
+                post.step(fake_y, data.get("part") if isinstance(data, dict) else None)
         from . import ops
         ops.check_errors(dev)
         n = self.dataset.observed_len + post.idx + self.forecast_len - 1      # rows written so far

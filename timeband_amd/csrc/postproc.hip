@@ -71,14 +71,14 @@ __global__ void denorm_kernel(const float* __restrict__ x, long n, int V, const 
 // (0 <= w < B) or from the history of the last Tf-1 windows (w < 0).  nanmedian / nanstd (ddof 0).
 constexpr int BAND_WAVES = 4;
 
-__global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __restrict__ pden, int B, int Tf, int V,
+__global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __restrict__ pden, int B, int Tf, int V, int nrows,
                                                                const float* __restrict__ hist, int nhist,
                                                                const double* __restrict__ dmin, const double* __restrict__ dmax,
                                                                double* __restrict__ med, double* __restrict__ sd) {
   extern __shared__ float vals_all[];   // [BAND_WAVES][Tf]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long item = (long)blockIdx.x * BAND_WAVES + wave;
-  const long nitems = (long)(B + Tf - 1) * V;
+  const long nitems = (long)nrows * V;
   float* vals = vals_all + (size_t)wave * Tf;
   __shared__ float s_med[BAND_WAVES][2];
   const bool live = item < nitems;
@@ -167,12 +167,12 @@ __device__ __forceinline__ void bitonic_sort(float (&a)[NP]) {
 }
 
 template <int NP>
-__global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V,
+__global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V, int nrows,
                                                         const float* __restrict__ hist, int nhist,
                                                         const double* __restrict__ dmin, const double* __restrict__ dmax,
                                                         double* __restrict__ med, double* __restrict__ sd) {
   const long item = (long)blockIdx.x * 256 + threadIdx.x;
-  const long nitems = (long)(B + Tf - 1) * V;
+  const long nitems = (long)nrows * V;
   if (item >= nitems) return;
   const int r = (int)(item / V), v = (int)(item % V);
   float a[NP];
@@ -400,6 +400,45 @@ __global__ void metric_kernel(const double* __restrict__ tru, const double* __re
   }
 }
 
+// The same in two stages for data-parallel runs: the five sums of a batch's rows are additive over the ranks
+// (each holds the rows of its windows), the three scores are not.  sums = [sq err, unmasked, sum ne, sum |ne|, nonzero].
+__global__ void metric_sums_kernel(const double* __restrict__ tru, const double* __restrict__ pred,
+                                   const int* __restrict__ mask, long n, double esp, double* sums) {
+  __shared__ double sh[5][4];
+  double s[5] = {0, 0, 0, 0, 0};
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    if (mask[i] != 0) continue;
+    const double t = tru[i], p = pred[i];
+    s[0] += (t - p) * (t - p);
+    s[1] += 1.0;
+    if (t != 0.0) {
+      const double ne = (t - p) / (esp + t);
+      s[2] += ne;
+      s[3] += fabs(ne);
+      s[4] += 1.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < 5; ++k) {
+    double v = s[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) sh[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) sums[threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+
+// scores of k batches from their (globally summed) sums, in batch order: out[b][0..2], running[0..2] += them
+__global__ void metric_finish_kernel(const double* __restrict__ sums, int k, double* out, double* running) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int b = 0; b < k; ++b) {
+    const double* t = sums + 5 * b;
+    const double nme = t[2] / t[4], nmae = t[3] / t[4], rmse = sqrt(t[0] / t[1]);
+    if (out) { out[3 * b] = nme; out[3 * b + 1] = nmae; out[3 * b + 2] = rmse; }
+    if (running) { running[0] += nme; running[1] += nmae; running[2] += rmse; }
+  }
+}
+
 inline int grid_for(long n, int cap = 4096) {
   long b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -449,45 +488,62 @@ int tb_denormalize(const float* x, long n, int V, const double* dmin, const doub
   return TB_OK;
 }
 
-// pden: (B,Tf,V) denormalised predictions of this batch.  hist_in/hist_out: (Tf-1,Tf,V) predictions of
-// the last Tf-1 windows before / after this batch (distinct buffers), nhist = valid windows in hist_in.
-// med/sd/lower/upper: (B+Tf-1, V) float64 outputs (sd is returned AFTER the smear).
-int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
-                   const double* dmin, const double* dmax, double band_width, double* med, double* sd, double* lower,
-                   double* upper, void* stream) {
+// pden: (B,Tf,V) predictions of this batch.  hist_in/hist_out: (Tf-1,Tf,V) predictions of the last Tf-1
+// windows before / after this batch (distinct buffers), nhist = valid windows in hist_in.
+// med/sd/lower/upper: float64 outputs of `rows_out` rows (sd is returned AFTER the smear).
+// tb_band_update_part: only the first rows_out <= B+Tf-1 rows, the std smear over the last Tf rows optional
+// (smear needs rows_out == B+Tf-1).  A data-parallel rank that is not the last of its global batch computes
+// its own B rows without the smear (the rows after them belong to its right neighbour).
+int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
+                        const double* dmin, const double* dmax, double band_width, double* med, double* sd,
+                        double* lower, double* upper, int rows_out, int smear, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0) return TB_OK;
   if (Tf < 2) return tb_set_error(TB_ERR_ARG, "band_update: forecast_len must be >= 2 (the reference divides by Tf-1)");
-  if (!pden || !hist_in || !hist_out || !med || !sd || !lower || !upper || hist_in == hist_out)
+  if (!pden || !hist_in || !med || !sd || !lower || !upper || hist_in == hist_out)
     return tb_set_error(TB_ERR_ARG, "band_update: bad pointer");
   if (nhist < 0 || nhist > Tf - 1) return tb_set_error(TB_ERR_ARG, "band_update: nhist out of range");
   if ((dmin == nullptr) != (dmax == nullptr)) return tb_set_error(TB_ERR_ARG, "band_update: dmin and dmax go together");
   const int R = B + Tf - 1;
-  const long nitems = (long)R * V;
+  if (rows_out < 1 || rows_out > R) return tb_set_error(TB_ERR_ARG, "band_update: rows_out %d outside [1, %d]", rows_out, R);
+  if (smear && rows_out != R) return tb_set_error(TB_ERR_ARG, "band_update: the std smear needs every row (rows_out == B+Tf-1)");
+  const long nitems = (long)rows_out * V;
   const size_t lds = (size_t)BAND_WAVES * Tf * sizeof(float);
   if (lds > 60 * 1024) return tb_set_error(TB_ERR_UNSUPPORTED, "band_update: forecast_len %d too long", Tf);
   tb_prof_begin(TB_K_BAND, s);
   if (Tf <= BAND_T_MAX) {
     const dim3 g((unsigned)((nitems + 255) / 256));
-    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
-    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
-    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
+    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
+    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
+    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
     TB_LAUNCH_CHECK("band_sort_kernel");
   } else {
     hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nitems + BAND_WAVES - 1) / BAND_WAVES)), dim3(64 * BAND_WAVES),
-                       lds, s, pden, B, Tf, V, hist_in, nhist, dmin, dmax, med, sd);
+                       lds, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
     TB_LAUNCH_CHECK("band_kernel");
   }
-  hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
-  TB_LAUNCH_CHECK("band_smear_kernel");
+  if (smear) {
+    hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
+    TB_LAUNCH_CHECK("band_smear_kernel");
+  }
   hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems)), dim3(256), 0, s, med, sd, nitems, band_width, lower,
                      upper);
   TB_LAUNCH_CHECK("band_finish_kernel");
-  hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for((long)(Tf - 1) * Tf * V)), dim3(256), 0, s, pden, B, Tf, V,
-                     hist_in, hist_out);
-  TB_LAUNCH_CHECK("hist_update_kernel");
+  if (hist_out) {
+    hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for((long)(Tf - 1) * Tf * V)), dim3(256), 0, s, pden, B, Tf, V,
+                       hist_in, hist_out);
+    TB_LAUNCH_CHECK("hist_update_kernel");
+  }
   tb_prof_end(TB_K_BAND, s);
   return TB_OK;
+}
+
+int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
+                   const double* dmin, const double* dmax, double band_width, double* med, double* sd, double* lower,
+                   double* upper, void* stream) {
+  if (B > 0 && !hist_out) return tb_set_error(TB_ERR_ARG, "band_update: bad pointer");
+  return tb_band_update_part(pden, B, Tf, V, hist_in, nhist, hist_out, dmin, dmax, band_width, med, sd, lower, upper,
+                             B + Tf - 1, 1, stream);
 }
 
 int tb_adjust_scan(int variant, const double* seed, const double* reals, const double* preds, const int* masks,
@@ -523,6 +579,23 @@ int tb_metrics(const double* tru, const double* pred, const int* mask, long n, d
   if (!tru || !pred || !mask || !out) return tb_set_error(TB_ERR_ARG, "metrics: null pointer");
   hipLaunchKernelGGL(metric_kernel, dim3(1), dim3(256), 0, s, tru, pred, mask, n, 1e-7, out, running);
   TB_LAUNCH_CHECK("metric_kernel");
+  return TB_OK;
+}
+
+int tb_metric_sums(const double* tru, const double* pred, const int* mask, long n, double* sums, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!tru || !pred || !mask || !sums) return tb_set_error(TB_ERR_ARG, "metric_sums: null pointer");
+  hipLaunchKernelGGL(metric_sums_kernel, dim3(1), dim3(256), 0, s, tru, pred, mask, n, 1e-7, sums);
+  TB_LAUNCH_CHECK("metric_sums_kernel");
+  return TB_OK;
+}
+
+int tb_metric_finish(const double* sums, int k, double* out, double* running, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k <= 0) return TB_OK;
+  if (!sums || (!out && !running)) return tb_set_error(TB_ERR_ARG, "metric_finish: null pointer");
+  hipLaunchKernelGGL(metric_finish_kernel, dim3(1), dim3(64), 0, s, sums, k, out, running);
+  TB_LAUNCH_CHECK("metric_finish_kernel");
   return TB_OK;
 }
 

@@ -59,22 +59,39 @@ class WindowSet:
         out = self.gather(idx, 1)
         return {k: v[0] for k, v in out.items()}
 
-    def loader(self, batch_size):
-        """Sequential (shuffle=False) batches, like the DataLoader the reference's caller builds."""
-        return _Loader(self, batch_size)
+    def loader(self, batch_size, rank=0, world=1):
+        """Sequential (shuffle=False) batches, like the DataLoader the reference's caller builds.
+        Data parallel (world > 1): `batch_size` is the GLOBAL batch; rank r gets its contiguous slice of each
+        global batch (dp.shard), and every batch carries `part` = (offset of the slice, windows in the global
+        batch) for the halo logic of the post-processing."""
+        return _Loader(self, batch_size, rank, world)
 
 
 class _Loader:
-    def __init__(self, ws, batch_size):
-        self.ws, self.batch_size = ws, int(batch_size)
+    def __init__(self, ws, batch_size, rank=0, world=1):
+        self.ws, self.batch_size, self.rank, self.world = ws, int(batch_size), int(rank), int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("loader: rank outside the world")
 
     def __len__(self):
         return (len(self.ws) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
+        from . import dp
         n = len(self.ws)
         for s in range(0, n, self.batch_size):
-            yield self.ws.gather(s, min(self.batch_size, n - s))
+            k = min(self.batch_size, n - s)
+            if self.world == 1:
+                yield self.ws.gather(s, k)
+                continue
+            if k < self.world:          # fewer windows than ranks: every rank runs the whole (tail) batch
+                batch = self.ws.gather(s, k)
+                batch["part"] = (0, k, True)
+            else:
+                lo, hi = dp.shard(k, self.rank, self.world)
+                batch = self.ws.gather(s + lo, hi - lo)
+                batch["part"] = (lo, k, False)
+            yield batch
 
 
 class TIMEBANDDataset:

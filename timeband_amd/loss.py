@@ -30,10 +30,15 @@ class TIMEBANDLoss:
             self._running.zero_()
         return self.loss()
 
-    def gen_loss(self, true, pred, DGx):
+    def gen_loss(self, true, pred, DGx, presum=None):
+        """`presum` (data parallel, optional): recon_presum(true, pred) started earlier, so the all-reduce of
+        the batch-global gradient-penalty norm runs under the discriminator pass."""
         total, _ = ops.gen_loss(true, pred, DGx, self.l1_weight, self.l2_weight, self.gp_weight,
-                                self._run(pred.device))
+                                self._run(pred.device), presum)
         return total
+
+    def recon_presum(self, true, pred):
+        return ops.recon_presum(true, pred) if ops.dp.active() else None
 
     def dis_loss(self, true, pred, Dy, DGx, critic: bool = False):
         if critic:
@@ -45,7 +50,13 @@ class TIMEBANDLoss:
     def _sums(self):
         if self._running is None:
             return [0.0] * 8
-        return self._running.tolist()      # the one host sync, at logging time
+        run = self._running
+        if ops.dp.active():
+            # data parallel: the adversarial terms (real, fake, G_) were accumulated as this rank's SHARE of the
+            # global means -- sum them over the ranks; l1 / l2 / gp come from globally reduced sums already
+            run = run.clone()
+            ops.dp.all_reduce(run[0:3])
+        return run.tolist()      # the one host sync, at logging time
 
     @property
     def errD_real(self):

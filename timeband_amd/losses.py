@@ -13,9 +13,8 @@ class _GanLossFn(torch.autograd.Function):
         ops._need_cuda(p)
         p = ops._f32c(p)
         rt = ops.Runtime.get(p.device)
-        W = ops._world()
-        sums = ops._loss_sums(p if real else None, None if real else p, None, None, rt)
-        n = float(p.numel() * W)
+        sums = ops._loss_sums(p if real else None, None if real else p, None, None, rt)   # all-reduced under DP
+        n = ops.dp.count_scale(p.numel())
         if wgan:
             val = -sums[2] / n if real else sums[3] / n
         else:

@@ -10,12 +10,14 @@ class TIMEBANDMetric:
         self.__dict__ = {**config, **self.__dict__}
         self.esp = 1e-7
         self._running = None
+        self._pending = []
         self.init_score()
 
     def set_config(self, config: dict):
         self.__dict__ = {**config, **self.__dict__}
 
     def init_score(self):
+        self._pending = []
         if self._running is not None:
             self._running.zero_()
         return self.score()
@@ -31,10 +33,24 @@ class TIMEBANDMetric:
         return f(true), f(pred), torch.as_tensor(mask).to(device=device, dtype=torch.int32).contiguous()
 
     def update(self, true, pred, mask):
-        """All three scores of one batch in one launch, added to the running sums; no host sync."""
+        """All three scores of one batch in one launch, added to the running sums; no host sync.
+        Data parallel: each rank holds the rows of its own windows; the scores are ratios of sums over ALL rows of
+        the global batch, so only the five additive sums are taken here -- they are summed over the ranks and
+        turned into scores when the running values are read (one all-reduce per pass, `_flush`)."""
         dev = pred.device if torch.is_tensor(pred) and pred.is_cuda else torch.device(self.device)
         t, p, m = self._prep(true, pred, mask, dev)
+        if ops.dp.active():
+            self._pending.append(ops.metric_sums(t, p, m))
+            self._run(dev)
+            return None
         return ops.metrics(t, p, m, self._run(dev))
+
+    def _flush(self):
+        if self._pending:
+            sums = torch.stack(self._pending)
+            self._pending = []
+            ops.dp.all_reduce(sums)
+            ops.metric_finish(sums, self._running)
 
     # the reference's per-score entry points (metric.py:30-61): each returns the batch score (host float)
     def _one(self, k, true, pred, mask):
@@ -54,6 +70,7 @@ class TIMEBANDMetric:
         return self._one(2, true, pred, mask)
 
     def _sums(self):
+        self._flush()
         return [0.0, 0.0, 0.0] if self._running is None else self._running.tolist()
 
     @property

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, dp
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 
@@ -94,6 +94,19 @@ def _slots(need, *params):
     return out if any(s is not None for s in out) else None
 
 
+# Data parallel: armed dp.GradReducer objects hear which parameters' gradients have just been ENQUEUED on
+# the current stream (only the slot path adds in place; gradients returned to autograd land later, and the
+# reducer's finish() covers them).
+_REDUCERS = []
+
+
+def grads_enqueued(slots, params):
+    if _REDUCERS and slots is not None:
+        done = [p for s_, p in zip(slots, params) if s_ is not None]
+        for r in list(_REDUCERS):
+            r.notify(done)
+
+
 # ----------------------------------------------------------------------------------------------
 # LSTM layer
 # ----------------------------------------------------------------------------------------------
@@ -152,6 +165,7 @@ class _LSTMLayerFn(torch.autograd.Function):
                   _ptr(dx), _ptr(dw_ih), _ptr(dw_hh), _ptr(db_ih), _ptr(db_hh), B, T, In, H,
                   1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
         if slots is not None:
+            grads_enqueued(slots, ctx.params)
             return dx, None, None, None, None, None
         return dx, dw_ih, dw_hh, db_ih, db_hh, None
 
@@ -218,6 +232,7 @@ class _LinearActFn(torch.autograd.Function):
         _lib.call("tb_linear_bwd", _ptr(dz), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, N,
                   1 if slots is not None else 0, _ptr(ws), ws.numel(), _stream())
         if slots is not None:
+            grads_enqueued(slots, ctx.params)
             return dx, None, None, None
         return dx, dW, db, None
 
@@ -258,6 +273,7 @@ class _HeadFn(torch.autograd.Function):
         _lib.call("tb_head_bwd", _ptr(dy), _ptr(y), _ptr(x), _ptr(W), _ptr(dx), _ptr(dW), _ptr(db), M, K, ctx.act,
                   1 if slots is not None else 0, _ptr(ws), ws.numel(), _stream())
         if slots is not None:
+            grads_enqueued(slots, ctx.params)
             return dx, None, None, None
         return dx, dW, db, None
 
@@ -277,41 +293,51 @@ def linear_act(x2d, W, b, act=ACT_NONE):
 # ----------------------------------------------------------------------------------------------
 # Losses
 # ----------------------------------------------------------------------------------------------
-_REPLICATED = False
-
-
-class replicated:
-    """Context: every rank runs the SAME batch (e.g. a critic batch that does not divide by the
-    world size).  Losses then use local counts and nothing is all-reduced: the kernels are
-    deterministic, so all ranks take bit-identical steps."""
-
-    def __enter__(self):
-        global _REPLICATED
-        self._old, _REPLICATED = _REPLICATED, True
-
-    def __exit__(self, *exc):
-        global _REPLICATED
-        _REPLICATED = self._old
+# Data parallel (dp.py): every rank holds a contiguous share of the global batch.  The gradient kernels
+# divide by GLOBAL element counts (dp.count_scale), so summed gradients are exact.  Only the reconstruction
+# sums behind the gradient penalty -- (1 - ||true - pred||)^2 / B with the norm over the WHOLE batch,
+# loss.py:136-141 -- have to be global before backward; `recon_presum` starts their all-reduce as soon as the
+# generator's output exists, under the discriminator pass.  The adversarial sums stay rank-local: the
+# returned loss value carries this rank's share of those terms (their gradients need no sum), and the
+# logging sums are made global when they are read (TIMEBANDLoss.loss).
+replicated = dp.replicated
 
 
 def _world():
-    import torch.distributed as dist
-    if not _REPLICATED and dist.is_available() and dist.is_initialized():
-        return dist.get_world_size()
-    return 1
+    return dp.world()
 
 
-def _loss_sums(Dy, DGx, tru, pred, rt):
+def _loss_sums(Dy, DGx, tru, pred, rt, reduce=True):
     lib = _lib.load()
     sums = torch.empty(8, dtype=torch.float64, device=rt.device)
     ws = rt.workspace(lib.tb_loss_workspace_bytes())
     _lib.call("tb_loss_sums", _ptr(Dy), 0 if Dy is None else Dy.numel(), _ptr(DGx),
               0 if DGx is None else DGx.numel(), _ptr(tru), _ptr(pred), 0 if pred is None else pred.numel(),
               _ptr(sums), _ptr(ws), ws.numel(), _stream())
-    if _world() > 1:
-        import torch.distributed as dist
-        dist.all_reduce(sums)          # the gradient-penalty norm is batch-global (loss.py:136-141)
+    if reduce and dp.active():
+        dp.all_reduce(sums)
     return sums
+
+
+class ReconPresum:
+    """sum huber(pred - true), sum (pred - true)^2 of this rank's windows, all-reduce in flight."""
+
+    def __init__(self, tru, pred):
+        _need_cuda(tru, pred)
+        tru, pred = _f32c(tru.detach()), _f32c(pred.detach())
+        rt = Runtime.get(pred.device)
+        self.sums = _loss_sums(None, None, tru, pred, rt, reduce=False)
+        self.handle = dp.all_reduce_async(self.sums[4:6]) if dp.active() else None
+
+    def get(self):
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+        return self.sums
+
+
+def recon_presum(tru, pred):
+    return ReconPresum(tru, pred)
 
 
 class _DisLossFn(torch.autograd.Function):
@@ -322,18 +348,20 @@ class _DisLossFn(torch.autograd.Function):
         _need_cuda(Dy, DGx, tru, pred)
         Dy, DGx = _f32c(Dy), _f32c(DGx)
         rt = Runtime.get(Dy.device)
-        W = _world()
         if critic:
             tru, pred = _f32c(tru), _f32c(pred)
-            sums = _loss_sums(Dy, DGx, tru, pred, rt)
+            # the penalty's gradient needs the global norm; without it (the trainer's critic step runs G without
+            # a graph) nothing does, and the critic's loss value -- never logged, loss.py:107-112 -- stays local
+            sums = _loss_sums(Dy, DGx, tru, pred, rt, reduce=bool(ctx.needs_input_grad[3]))
         else:
-            sums = _loss_sums(Dy, DGx, None, None, rt)
+            sums = _loss_sums(Dy, DGx, None, None, rt, reduce=False)
         out = torch.empty(8, dtype=torch.float32, device=Dy.device)
-        nP = float(pred.numel() * W) if critic else 1.0
-        batch = float(tru.shape[0] * W) if critic else 1.0
-        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, float(Dy.numel() * W), float(DGx.numel() * W),
+        nP = dp.count_scale(pred.numel()) if critic else 1.0
+        batch = dp.count_scale(tru.shape[0]) if critic else 1.0
+        nDy, nDGx = dp.count_scale(Dy.numel()), dp.count_scale(DGx.numel())
+        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, nDy, nDGx,
                   nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), _ptr(None if critic else running), _stream())
-        ctx.critic, ctx.gp_w, ctx.W = critic, gp_w, W
+        ctx.critic, ctx.gp_w, ctx.counts = critic, gp_w, (nDy, nDGx, nP, batch)
         ctx.save_for_backward(Dy, DGx, tru if critic else None, pred if critic else None, sums)
         total = torch.empty((), dtype=torch.float32, device=out.device)
         total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
@@ -343,23 +371,20 @@ class _DisLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _gout):
         Dy, DGx, tru, pred, sums = ctx.saved_tensors
-        W = ctx.W
+        nDy, nDGx, nP, batch = ctx.counts
         up = _f32c(gtotal)
         dDy = torch.empty_like(Dy) if ctx.needs_input_grad[0] else None
         dDGx = torch.empty_like(DGx) if ctx.needs_input_grad[1] else None
         wgan = 1 if ctx.critic else 0
         if dDy is not None:
-            _lib.call("tb_gan_loss_grad", _ptr(Dy), Dy.numel(), float(Dy.numel() * W), 1, wgan, _ptr(up), _ptr(dDy),
-                      _stream())
+            _lib.call("tb_gan_loss_grad", _ptr(Dy), Dy.numel(), nDy, 1, wgan, _ptr(up), _ptr(dDy), _stream())
         if dDGx is not None:
-            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), float(DGx.numel() * W), 0, wgan, _ptr(up),
-                      _ptr(dDGx), _stream())
+            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), nDGx, 0, wgan, _ptr(up), _ptr(dDGx), _stream())
         dpred = None
         if ctx.critic and ctx.needs_input_grad[3]:
             dpred = torch.empty_like(pred)
-            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), float(pred.numel() * W),
-                      float(tru.shape[0] * W), _ptr(sums), 0.0, 0.0, float(ctx.gp_w), _ptr(up), _ptr(dpred), 0,
-                      _stream())
+            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), nP, batch, _ptr(sums), 0.0, 0.0,
+                      float(ctx.gp_w), _ptr(up), _ptr(dpred), 0, _stream())
         return dDy, dDGx, None, dpred, None, None, None
 
 
@@ -367,17 +392,23 @@ class _GenLossFn(torch.autograd.Function):
     """TIMEBANDLoss.gen_loss (loss.py:93-104): adversarial term with the FAKE label + l1 + l2 + gp."""
 
     @staticmethod
-    def forward(ctx, tru, pred, DGx, l1_w, l2_w, gp_w, running):
+    def forward(ctx, tru, pred, DGx, l1_w, l2_w, gp_w, running, presum):
         _need_cuda(tru, pred, DGx)
         tru, pred, DGx = _f32c(tru), _f32c(pred), _f32c(DGx)
         rt = Runtime.get(pred.device)
-        W = _world()
-        sums = _loss_sums(None, DGx, tru, pred, rt)
+        if presum is not None:
+            sums = _loss_sums(None, DGx, None, None, rt, reduce=False)
+            sums[4:6].copy_(presum.get()[4:6])      # the global reconstruction sums, reduced under the D pass
+        else:
+            sums = _loss_sums(None, DGx, tru, pred, rt, reduce=False)
+            if dp.active():
+                dp.all_reduce(sums[4:6])
         out = torch.empty(8, dtype=torch.float32, device=pred.device)
-        _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, float(DGx.numel() * W), float(pred.numel() * W),
-                  float(tru.shape[0] * W), float(l1_w), float(l2_w), float(gp_w), _ptr(out), _ptr(running), _stream())
+        nDGx, nP, batch = dp.count_scale(DGx.numel()), dp.count_scale(pred.numel()), dp.count_scale(tru.shape[0])
+        _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, nDGx, nP, batch, float(l1_w), float(l2_w), float(gp_w),
+                  _ptr(out), _ptr(running), _stream())
         ctx.w = (l1_w, l2_w, gp_w)
-        ctx.W = W
+        ctx.counts = (nDGx, nP, batch)
         ctx.save_for_backward(tru, pred, DGx, sums)
         total = torch.empty((), dtype=torch.float32, device=out.device)
         total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
@@ -388,27 +419,25 @@ class _GenLossFn(torch.autograd.Function):
     def backward(ctx, gtotal, _gout):
         tru, pred, DGx, sums = ctx.saved_tensors
         l1_w, l2_w, gp_w = ctx.w
-        W = ctx.W
+        nDGx, nP, batch = ctx.counts
         up = _f32c(gtotal)
         dpred = dDGx = None
         if ctx.needs_input_grad[1]:
             dpred = torch.empty_like(pred)
-            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), float(pred.numel() * W),
-                      float(tru.shape[0] * W), _ptr(sums), float(l1_w), float(l2_w), float(gp_w), _ptr(up),
-                      _ptr(dpred), 0, _stream())
+            _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), nP, batch, _ptr(sums), float(l1_w),
+                      float(l2_w), float(gp_w), _ptr(up), _ptr(dpred), 0, _stream())
         if ctx.needs_input_grad[2]:
             dDGx = torch.empty_like(DGx)
-            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), float(DGx.numel() * W), 0, 0, _ptr(up), _ptr(dDGx),
-                      _stream())
-        return None, dpred, dDGx, None, None, None, None
+            _lib.call("tb_gan_loss_grad", _ptr(DGx), DGx.numel(), nDGx, 0, 0, _ptr(up), _ptr(dDGx), _stream())
+        return None, dpred, dDGx, None, None, None, None, None
 
 
 def dis_loss(Dy, DGx, tru=None, pred=None, critic=False, gp_w=0.0, running=None):
     return _DisLossFn.apply(Dy, DGx, tru, pred, critic, gp_w, running)
 
 
-def gen_loss(tru, pred, DGx, l1_w, l2_w, gp_w, running=None):
-    return _GenLossFn.apply(tru, pred, DGx, l1_w, l2_w, gp_w, running)
+def gen_loss(tru, pred, DGx, l1_w, l2_w, gp_w, running=None, presum=None):
+    return _GenLossFn.apply(tru, pred, DGx, l1_w, l2_w, gp_w, running, presum)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -440,22 +469,23 @@ def denormalize(x, dmin, dmax):
     return out
 
 
-def band_update(pden, hist_in, nhist, hist_out, band_width, dmin=None, dmax=None):
-    """dmin / dmax given: `pden` and the history hold NORMALISED predictions, denormalised as they are read."""
+def band_update(pden, hist_in, nhist, hist_out, band_width, dmin=None, dmax=None, rows_out=None, smear=True):
+    """dmin / dmax given: `pden` and the history hold NORMALISED predictions, denormalised as they are read.
+    rows_out / smear: tb_band_update_part (a data-parallel rank's own rows); hist_out may then be None."""
     _need_cuda(pden, hist_in, hist_out)
     if dmin is not None:
         dmin, dmax = _c(dmin, torch.float64), _c(dmax, torch.float64)
     pden = _f32c(pden)
     B, Tf, V = pden.shape
     for h in (hist_in, hist_out):
-        if h.shape != (Tf - 1, Tf, V) or not h.is_contiguous() or h.dtype != torch.float32:
+        if h is not None and (h.shape != (Tf - 1, Tf, V) or not h.is_contiguous() or h.dtype != torch.float32):
             raise RuntimeError("band_update: history buffers must be contiguous float32 (Tf-1,Tf,V)")
-    R = B + Tf - 1
+    R = B + Tf - 1 if rows_out is None else int(rows_out)
     mk = lambda: torch.empty(R, V, dtype=torch.float64, device=pden.device)
     med, sd, lower, upper = mk(), mk(), mk(), mk()
-    _lib.call("tb_band_update", _ptr(pden), B, Tf, V, _ptr(hist_in), int(nhist), _ptr(hist_out), _ptr(dmin), _ptr(dmax),
-              float(band_width),
-              _ptr(med), _ptr(sd), _ptr(lower), _ptr(upper), _stream())
+    _lib.call("tb_band_update_part", _ptr(pden), B, Tf, V, _ptr(hist_in), int(nhist), _ptr(hist_out), _ptr(dmin),
+              _ptr(dmax), float(band_width), _ptr(med), _ptr(sd), _ptr(lower), _ptr(upper), R, 1 if smear else 0,
+              _stream())
     return med, lower, upper
 
 
@@ -490,6 +520,27 @@ def metrics(reals, preds, masks, running=None):
         raise RuntimeError("metrics: shape mismatch")
     out = torch.empty(3, dtype=torch.float64, device=preds.device)
     _lib.call("tb_metrics", _ptr(reals), _ptr(preds), _ptr(masks), preds.numel(), _ptr(out), _ptr(running), _stream())
+    return out
+
+
+def metric_sums(reals, preds, masks):
+    """The five additive sums behind NME / NMAE / RMSE of one batch's rows (data parallel: summed over ranks)."""
+    _need_cuda(reals, preds, masks)
+    reals, preds, masks = _c(reals, torch.float64), _c(preds, torch.float64), _c(masks, torch.int32)
+    if reals.shape != preds.shape or masks.shape != preds.shape:
+        raise RuntimeError("metrics: shape mismatch")
+    out = torch.empty(5, dtype=torch.float64, device=preds.device)
+    _lib.call("tb_metric_sums", _ptr(reals), _ptr(preds), _ptr(masks), preds.numel(), _ptr(out), _stream())
+    return out
+
+
+def metric_finish(sums, running=None):
+    """Scores (k,3) of k batches from their sums (k,5); running[3] += each of them, in order."""
+    _need_cuda(sums)
+    sums = _c(sums, torch.float64)
+    k = sums.shape[0]
+    out = torch.empty(k, 3, dtype=torch.float64, device=sums.device)
+    _lib.call("tb_metric_finish", _ptr(sums), k, _ptr(out), _ptr(running), _stream())
     return out
 
 

@@ -5,9 +5,11 @@ source/trainer.py:95-98 -- Adam re-created every epoch; :143-144 -- RMSprop re-c
 buffer, so an optimizer step is one kernel launch and a data-parallel gradient exchange is one
 all-reduce with no packing.  Stock torch.optim optimizers still work on the same parameters.
 """
+import os
+
 import torch
 
-from . import ops
+from . import dp, ops
 
 
 class FlatParams:
@@ -29,7 +31,42 @@ class FlatParams:
             p.data = self.data[off:off + k].view(p.shape)
             p.grad = self.grad[off:off + k].view(p.shape)
             p._tb_grad_slot = p.grad        # the backward kernels add into it directly (ops._slots)
+            p._tb_flat = self
             off += k
+        self.buckets = self._make_buckets(module)
+
+    def _make_buckets(self, module):
+        """Contiguous [lo, hi) ranges of the flat buffer in the order backward completes them: the
+        top-level sub-modules in REVERSE registration order (generator: dim_layer, seq_layer, lstm2 | lstm1
+        | lstm0), neighbours merged until a bucket holds at least TB_DP_BUCKET floats (default 64 Ki: a
+        smaller message costs a collective's latency for nothing)."""
+        min_floats = int(os.environ.get("TB_DP_BUCKET", 65536))
+        groups, off = [], 0           # [name, lo, hi, params] in registration order
+        for name, p in module.named_parameters():
+            top = name.split(".")[0]
+            if not groups or groups[-1][0] != top:
+                groups.append([top, off, off, []])
+            groups[-1][2] = off + p.numel()
+            groups[-1][3].append(p)
+            off += p.numel()
+        buckets, cur = [], None
+        for top, lo, hi, ps in reversed(groups):
+            if cur is None:
+                cur = dict(lo=lo, hi=hi, params=list(ps), names=[top])
+            else:
+                cur["lo"] = lo
+                cur["params"] += ps
+                cur["names"].append(top)
+            if cur["hi"] - cur["lo"] >= min_floats:
+                buckets.append(cur)
+                cur = None
+        if cur is not None:
+            buckets.append(cur)
+        for i, b in enumerate(buckets):
+            b["nparams"] = len(b["params"])
+            for p in b["params"]:
+                p._tb_bucket = i
+        return buckets
 
     def check(self):
         """Parameters / grads must still alias the flat buffers (e.g. nobody set .grad = None)."""
@@ -58,15 +95,30 @@ class _FlatOptimizer:
     def __init__(self, module, lr):
         self.flat = flatten(module)
         self.lr = lr
+        self._reducer = None
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.check()
         self.flat.grad.zero_()
 
+    # Data parallel: sum all-reduce of the gradient buffer (the loss kernels already divide by GLOBAL counts).
+    # begin_reduce() BEFORE the last backward pass that adds into this network's gradients: its buckets are
+    # then reduced on the communication stream as BPTT completes them; all_reduce_grads() (before step())
+    # reduces what has not been and waits for all of it.
+    def begin_reduce(self):
+        if dp.active():
+            self._reducer = dp.GradReducer(self.flat)
+            self._reducer.arm()
+
     def all_reduce_grads(self):
-        if ops._world() > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.flat.grad)      # sum: the loss kernels already divide by GLOBAL counts
+        if not dp.active():
+            self._reducer = None
+            return
+        if self._reducer is None:
+            self._reducer = dp.GradReducer(self.flat)
+            self._reducer.arm()
+        self._reducer.finish()
+        self._reducer = None
 
 
 class FusedAdam(_FlatOptimizer):

@@ -4,10 +4,20 @@ Restates the per-batch tail of the reference (source/trainer.py:202-212, cleaner
 predictor.py:86-96) without leaving the GPU: denormalise -> band (median/std over horizons, HIP)
 -> adjust (sequential scan, HIP).  The reference's growing `outputs` array is replaced by absolute
 row positions: target row p of the batch that starts at window idx is data row To + idx + p.
+
+Data parallel (no counterpart in the reference).  Rank r holds the predictions of a
+contiguous slice [lo, lo+b) of the global batch, so it owns the band / adjust rows [idx+lo, idx+lo+b) --
+the last rank also the forecast_len-1 overhang rows behind the batch.  A row's band needs the predictions
+of the forecast_len-1 windows before it: every rank sends its last forecast_len-1 windows' predictions to its
+right neighbour (one ring shift; what wraps round to rank 0 is the history for the NEXT global batch).
+The adjust scan is a chain along the rows: its one-row carry travels down the ranks, and from the last
+rank back to rank 0 as the next batch's seed row (the reference seeds each batch with the LAST overhang
+row of the previous one, trainer.py:209).  Slices shorter than forecast_len-1 windows fall back to an
+all-gather of the predictions and the single-rank arithmetic on every rank.
 """
 import torch
 
-from . import ops
+from . import dp, ops
 
 
 class BandAdjust:
@@ -26,6 +36,7 @@ class BandAdjust:
         self.cur = 0
         self.nhist = 0
         self.idx = 0
+        self._rank0_state = False      # data parallel: after a sharded step only rank 0 holds hist / last_row
         self.restart_pass()
 
     def restart_pass(self):
@@ -38,7 +49,33 @@ class BandAdjust:
                                                                 dtype=torch.float64, device=d.observed_dev.device)])
             self.outputs, self.lower_bands, self.upper_bands = mk(), mk(), mk()
 
-    def step(self, fake_y):
+    def step(self, fake_y, part=None):
+        """part (data parallel): (lo, n, replicated) -- fake_y holds windows [lo, lo + len(fake_y)) of the global
+        batch of n windows that starts at self.idx (replicated: every rank holds all n)."""
+        if part is not None and dp.active() and not part[2]:
+            lo, n = int(part[0]), int(part[1])
+            Tf = fake_y.shape[1]
+            W = dp.world()
+            if min(dp.shard(n, r, W)[1] - dp.shard(n, r, W)[0] for r in range(W)) >= Tf - 1:
+                return self._step_shard(fake_y, lo, n)
+            fake_y = dp.all_gather_cat(fake_y.detach().contiguous())     # short slices: the whole batch everywhere
+            self._sync_state()
+        return self._step_all(fake_y)
+
+    def _sync_state(self):
+        """Before a step that every rank runs in full: the band history and the adjust seed row live on rank 0
+        after sharded steps (the ring shift and the carry end there) -- hand them to everybody."""
+        if not self._rank0_state:
+            return
+        d = self.ds
+        dp.broadcast(self.hist[self.cur], 0)
+        self.nhist = d.forecast_len - 1
+        if self.last_row is None:
+            self.last_row = torch.empty(d.decode_dim, dtype=torch.float64, device=self.hist[0].device)
+        self.last_row = dp.broadcast(self.last_row.contiguous(), 0)
+        self._rank0_state = False
+
+    def _step_all(self, fake_y):
         d = self.ds
         B, Tf, V = fake_y.shape
         # the history holds normalised predictions: the band kernel denormalises as it gathers
@@ -54,10 +91,56 @@ class BandAdjust:
         seed = d.observed_dev[-1] if self.last_row is None else self.last_row
         target = ops.adjust_scan(self.variant, seed, reals, preds, masks, lower, upper, self.a, self.b)
         self.last_row = target[-1]
+        self._keep(self.idx, target, lower, upper)
+        self.idx += B
+        return reals, preds, masks, lower, upper, target
+
+    def _keep(self, first, target, lower, upper):
         if self.keep:
-            r0 = d.observed_len + self.idx
+            r0 = self.ds.observed_len + first
+            n = target.shape[0]
             self.outputs[r0:r0 + n] = target
             self.lower_bands[r0:r0 + n] = lower
             self.upper_bands[r0:r0 + n] = upper
-        self.idx += B
+
+    def _step_shard(self, fake_y, lo, n):
+        """This rank's rows of the global batch [idx, idx + n): halo in from the left, carry down the ranks."""
+        d = self.ds
+        b, Tf, V = fake_y.shape
+        W, r = dp.world(), dp.rank()
+        last = r == W - 1
+        fake_y = fake_y.detach().contiguous()
+        # band halo: my last Tf-1 windows -> right neighbour; rank 0 keeps what wraps round for the next batch
+        halo = torch.empty(Tf - 1, Tf, V, dtype=torch.float32, device=fake_y.device)
+        dp.ring_shift(fake_y[b - (Tf - 1):], halo)
+        if r == 0:
+            hist_in, nhist = self.hist[self.cur], self.nhist
+            self.hist[self.cur ^ 1] = halo
+            self.cur ^= 1
+            self.nhist = Tf - 1
+        else:
+            hist_in, nhist = halo, Tf - 1
+        rows = b + Tf - 1 if last else b
+        first = self.idx + lo
+        if first + rows > d.forecast_dev.shape[0]:
+            raise RuntimeError("post-processing ran past the end of the series")
+        preds, lower, upper = ops.band_update(fake_y, hist_in, nhist, None, self.w, d.dmin_dev, d.dmax_dev,
+                                              rows_out=rows, smear=last)
+        reals = d.forecast_dev[first:first + rows]
+        masks = d.missing_dev[first:first + rows]
+        # adjust carry: the row before my first one
+        if r == 0:
+            seed = d.observed_dev[-1] if self.last_row is None else self.last_row
+        else:
+            seed = dp.recv_row(torch.empty(V, dtype=torch.float64, device=fake_y.device), r - 1)
+        target = ops.adjust_scan(self.variant, seed, reals, preds, masks, lower, upper, self.a, self.b)
+        if W == 1:
+            self.last_row = target[-1]
+        else:
+            dp.send_row(target[-1].contiguous(), (r + 1) % W)
+            if r == 0:  # the last rank's last overhang row seeds the next global batch (trainer.py:209)
+                self.last_row = dp.recv_row(torch.empty(V, dtype=torch.float64, device=fake_y.device), W - 1)
+        self._keep(first, target, lower, upper)
+        self.idx += n
+        self._rank0_state = W > 1
         return reals, preds, masks, lower, upper, target

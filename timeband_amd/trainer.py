@@ -11,15 +11,18 @@ semantics as the reference's Gen-A trainer, including its quirks
 What changes is where the work runs: windows are gathered on the device, losses / optimizers /
 band / adjust / scores are HIP kernels, and nothing is copied to the host inside the batch loop
 (the reference syncs on `.cpu()` and `.numpy()` every batch, trainer.py:202,223-234).
-Data parallel: one process per GPU, every rank holds the same parameters and steps on its
-contiguous shard of each global batch; gradients are summed with ONE all-reduce per network over
-the flat gradient buffer (RCCL over xGMI), the gradient-penalty norm with one 8-double all-reduce.
+Data parallel (dp.py): one process per GPU, every rank holds the same parameters and steps on its
+contiguous slice of each global batch (`trainset.loader(batch_size, rank, world)`); each network's flat
+gradient buffer is summed in buckets, in the order BPTT completes them, on a communication stream
+(RCCL over xGMI) while the earlier layers' BPTT still runs; the two sums behind the batch-global
+gradient-penalty norm are all-reduced under the discriminator pass; band / adjust exchange a halo with the
+neighbouring rank (postprocess.py).
 """
 import os
 
 import torch
 
-from . import ops
+from . import dp, ops
 from .loss import TIMEBANDLoss
 from .metric import TIMEBANDMetric
 from .model import TIMEBANDModel
@@ -113,33 +116,34 @@ class TIMEBANDTrainer:
         self._critic_opt.zero_grad()
         Dy, DGx = netD.pair(true_y, fake_y)
         errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx, critic=True)
+        self._critic_opt.begin_reduce()
         errD.backward()
         self._critic_opt.all_reduce_grads()
         self._critic_opt.step()
 
     @staticmethod
     def _shard_critic(cx, cy):
-        """Data parallel: every rank draws the same critic batch (same numpy seed).  If its size
-        divides by the world size each rank keeps its contiguous slice (sharded, all-reduced);
-        otherwise all ranks run the whole batch redundantly (replicated, nothing reduced)."""
-        W = ops._world()
-        if W == 1:
+        """Data parallel: every rank draws the same critic batch (same numpy seed).  If it has at least one
+        window per rank each rank keeps its contiguous slice (sharded, gradients all-reduced); otherwise all
+        ranks run the whole batch redundantly (replicated, nothing reduced)."""
+        if not dp.active():
             return cx, cy, True
-        import torch.distributed as dist
-        n, r = cx.shape[0], dist.get_rank()
-        if n % W:
+        n = cx.shape[0]
+        lo, hi = dp.shard(n)
+        if n < dp.world():
             return cx, cy, False
-        k = n // W
-        return cx[r * k:(r + 1) * k].contiguous(), cy[r * k:(r + 1) * k].contiguous(), True
+        return cx[lo:hi].contiguous(), cy[lo:hi].contiguous(), True
 
-    def iteration(self, true_x, true_y, training=True, critic_batches=None):
+    def iteration(self, true_x, true_y, training=True, critic_batches=None, n_global=None):
         """trainer.py:142-194.  `critic_batches`: iterable of (x, y) critic draws (default: `critic`
-        draws from dataset.get_random()).  Returns the G-phase fake_y."""
+        draws from dataset.get_random()).  Data parallel: true_x / true_y are this rank's slice of a global
+        batch of `n_global` windows (default: equal slices on every rank).  Returns the G-phase fake_y."""
         netD, netG = self.models.netD, self.models.netG
         overlap = self.overlap and training and true_x.is_cuda
         # which parts overlap (TB_OVERLAP bit mask, default 5): 1 = D-phase generator forward under the
         # critic step, 2 = G-phase generator forward under the D-phase backward, 4 = graph cut at fake_y
-        # (generator backward on a side stream)
+        # (the generator's share of errD.backward() runs on the stream of its forward -- the side stream
+        # with bit 1 -- under the G phase's forward and discriminator pass)
         ov1, ov2, ov4 = ((overlap and bool(self.overlap_mask & b)) for b in (1, 2, 4))
         share = self.share_gpass and training
         if share:
@@ -150,8 +154,12 @@ class TIMEBANDTrainer:
                 self._side = (torch.cuda.Stream(true_x.device), torch.cuda.Stream(true_x.device))
                 # G's parameter gradients are produced on the side streams and accumulated into leaves
                 # created on the main one: intended here
-                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if quiet is not None:
+                    quiet(False)
             s1, s2 = self._side
+        nloc = true_x.shape[0]
+        counts = lambda: dp.batch_counts(nloc, nloc * dp.world() if n_global is None else n_global)
         if ov1:
             s1.wait_stream(main)
             with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step
@@ -162,22 +170,24 @@ class TIMEBANDTrainer:
             if critic_batches is None:
                 critic_batches = (self.dataset.get_random() for _ in range(self.critic))
             for cx, cy in critic_batches:
+                ncr = cx.shape[0]
                 cx, cy, shared = self._shard_critic(cx, cy)
                 if shared:
-                    self.critic_step(cx, cy)
+                    with dp.batch_counts(cx.shape[0], ncr):
+                        self.critic_step(cx, cy)
                 else:
-                    with ops.replicated():
+                    with dp.replicated():
                         self.critic_step(cx, cy)
         self.optimD.zero_grad()
         self.optimG.zero_grad()
         # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
-        with torch.set_grad_enabled(training):
+        with torch.set_grad_enabled(training), counts():
             if ov1:
                 main.wait_stream(s1)
             else:
                 fake_y = netG(true_x)
             if ov4 or share:
-                # cut the graph at fake_y: D's backward runs on this stream, G's (below) on the side one
+                # cut the graph at fake_y: D's backward runs on this stream, G's (below) on its forward's
                 fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
             Dy, DGx = netD.pair(true_y, fake_y)
             errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx)
@@ -187,6 +197,7 @@ class TIMEBANDTrainer:
                 fake_y2 = netG(true_x)
             fake_y2.record_stream(main)
         if training:
+            self.optimD.begin_reduce()           # D's gradients are complete after this backward pass
             errD.backward()
             if share:
                 dfake_dphase = fake_y.grad
@@ -194,8 +205,6 @@ class TIMEBANDTrainer:
                 s1.wait_stream(main)
                 with torch.cuda.stream(s1):
                     fake_g.backward(fake_y.grad)
-            self.optimD.all_reduce_grads()
-            self.optimD.step()
         # generator phase.  errG.backward() of the reference also accumulates into D's parameter
         # gradients (trainer.py:183-186); the next zero_grad (:146 / :160) clears them unread, so D's
         # weight gradients are not computed here -- only the path through D back to fake_y.
@@ -203,7 +212,7 @@ class TIMEBANDTrainer:
         for p in dparams:
             p.requires_grad_(False)
         try:
-            with torch.set_grad_enabled(training):
+            with torch.set_grad_enabled(training), counts():
                 if share:
                     fake_y = fake_g.detach().requires_grad_()
                 elif ov2:
@@ -211,13 +220,24 @@ class TIMEBANDTrainer:
                     fake_y = fake_y2
                 else:
                     fake_y = netG(true_x)
+                # data parallel: the all-reduce of the gradient-penalty norm's sums starts here and runs under
+                # the discriminator pass below
+                presum = self.losses.recon_presum(true_y, fake_y) if training else None
+                if training:
+                    # Adam(D) after the D-phase backward (trainer.py:179-180), placed behind the generator forward
+                    # -- which does not read D -- so that D's gradient all-reduce hides under it
+                    self.optimD.all_reduce_grads()
+                    self.optimD.step()
                 if ov4 and not share:
                     fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
                 DGx = netD(fake_y)
-                errG = self.losses.gen_loss(true_y, fake_y, DGx)
+                errG = self.losses.gen_loss(true_y, fake_y, DGx, presum=presum)
             if training:
+                if not (share or ov4):
+                    self.optimG.begin_reduce()   # errG.backward() runs through D into G: G's last backward pass
                 errG.backward()
                 if share:
+                    self.optimG.begin_reduce()
                     fake_g.backward(dfake_dphase + fake_y.grad)
                     if overlap:
                         main.wait_stream(s1)
@@ -225,6 +245,7 @@ class TIMEBANDTrainer:
                 elif ov4:    # G-phase generator backward after the D-phase one (both add into G's gradients)
                     s2.wait_stream(main)
                     s2.wait_stream(s1)
+                    self.optimG.begin_reduce()
                     with torch.cuda.stream(s2):
                         fake_g.backward(fake_y.grad)
                     main.wait_stream(s2)
@@ -241,7 +262,8 @@ class TIMEBANDTrainer:
 
     def train_step(self, epoch: int, dataset, training: bool = True):
         """One pass over `dataset` (any iterable of {"encoded","decoded"} batches); returns the mean
-        NMAE like trainer.py:236.  One host sync, at the end."""
+        NMAE like trainer.py:236.  One host sync, at the end.  Data parallel: `dataset` is
+        `windowset.loader(batch_size, rank, world)`, whose batches carry this rank's slice and its `part`."""
         if self.optimD is None:
             self.new_epoch()
         self.losses.init_loss()
@@ -252,8 +274,13 @@ class TIMEBANDTrainer:
         for i, data in enumerate(dataset):
             true_x = data["encoded"].to(dev)
             true_y = data["decoded"].to(dev)
-            fake_y = self.iteration(true_x, true_y, training)
-            reals, preds, masks, lower, upper, target = self.post.step(fake_y)
+            part = data.get("part") if isinstance(data, dict) else None
+            if part is not None and part[2]:
+                with dp.replicated():        # a tail batch with fewer windows than ranks: the same step everywhere
+                    fake_y = self.iteration(true_x, true_y, training)
+            else:
+                fake_y = self.iteration(true_x, true_y, training, n_global=None if part is None else part[1])
+            reals, preds, masks, lower, upper, target = self.post.step(fake_y, part)
             self.idx = self.post.idx
             if self.dashboard is not None and getattr(self.dashboard, "vis_opt", False):
                 self.dashboard.vis(true_y.shape[0], reals.cpu().numpy(), preds.cpu().numpy(), lower.cpu().numpy(),
