@@ -159,7 +159,7 @@ def main():
     from timeband_amd.dataset import WindowSet
     # the product's own sharding: global batches of B * world windows, this rank's contiguous slice of each
     # (weak scaling: B windows per GPU); whole batches only, cycled
-    loader = WindowSet(ds, trainset.w0, nbatches * B * world).loader(B * world, rank, world)
+    loader = WindowSet(ds, trainset.w0, nbatches * B * world, trainset.row0).loader(B * world, rank, world)
     state = {"it": iter(loader), "seen": 0}
 
     def step(i):

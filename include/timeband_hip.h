@@ -141,6 +141,20 @@ int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, doub
  *   2 source/predictor.py:106-125.
  *   seed (V) = the row before reals[0]; reals/preds/lower/upper (n,V) float64; masks (n,V) int32.
  * tb_metrics: NME / NMAE / RMSE of source/metric.py:30-73 -> out[3] (+= running[3], nullable). */
+/* tb_minmax: minmax_info, source/dataset.py:297-321 -- column min / max of the interpolated frame (rows, E)
+ *   float64 (callers pass the first int(len*split_rate) rows; NaN skipped like pandas).  init 0 folds into what
+ *   mn / mx hold (a frame streamed in row chunks); finish != 0 applies the reference's fix-ups (:311-312:
+ *   min == -inf -> max, then min == max -> max + 1).  Workspace tb_minmax_workspace_bytes(E).
+ * tb_normalize: normalize, source/dataset.py:216-227 -- 2*((x-min)/(max-min))-1 in float64; writes the float32
+ *   series the windows are cut from (utils/dataset.py:19-20 casts every window to float32) and/or the float64
+ *   frame of the reference's normalized.csv.
+ * tb_take_columns: the target columns of the frame (observed / forecast, source/dataset.py:130-133). */
+size_t tb_minmax_workspace_bytes(int E);
+int tb_minmax(const double* data, long rows, int E, double* mn, double* mx, int init, int finish, void* ws,
+              size_t ws_bytes, void* stream);
+int tb_normalize(const double* data, long rows, int E, const double* mn, const double* mx, float* out32, double* out64,
+                 void* stream);
+int tb_take_columns(const double* data, long rows, int E, const int* cols, int V, double* out, void* stream);
 int tb_window_gather(const float* series, long series_len, int E, const long* starts, long first, long stride,
                      int nwin, int To, int Tf, const int* target_cols, int V, float* enc, float* dec,
                      void* stream);

@@ -80,6 +80,26 @@ def test_interpolate_and_window_math_match_oracle():
         assert ds.n_windows() == len(O.window_starts(n, To, Tf, stride))
 
 
+def test_chunked_fill_matches_whole_frame_fill():
+    """from_arrays streams the frame in row chunks: forward fill with a carry row that starts at each column's
+    first valid value == ffill + bfill + fillna(0) over the whole frame (reference dataset.py:111-115)."""
+    from oracle import timeband_oracle as O
+    from timeband_amd.dataset import _ffill_chunk
+    rng = np.random.default_rng(1)
+    a = rng.normal(size=(97, 5))
+    a[rng.random((97, 5)) < 0.4] = np.nan
+    a[:40, 1] = np.nan         # leading gap longer than a chunk
+    a[:, 4] = np.nan           # empty column
+    want = O.interpolate(a)
+    first = np.array([col[~np.isnan(col)][0] if (~np.isnan(col)).any() else 0.0 for col in a.T])
+    for chunk in (7, 32, 200):
+        carry, parts = first.copy(), []
+        for r0 in range(0, len(a), chunk):
+            f, carry = _ffill_chunk(a[r0:r0 + chunk], carry)
+            parts.append(f)
+        np.testing.assert_array_equal(np.concatenate(parts), want)
+
+
 def test_time_feature_order():
     from timeband_amd import synthetic
     tf = synthetic.time_features(30, enabled=("month", "weekday", "day", "hour"))

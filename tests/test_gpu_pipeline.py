@@ -75,6 +75,62 @@ def test_dataset_matches_reference(world):
     assert len(ds.prepare_dataset(split=False)) == int(z["full_len"])
 
 
+def test_device_minmax_normalize_match_reference(world):
+    """tb_minmax / tb_normalize / tb_take_columns on the uploaded frame against the reference's own frame
+    (ds.normalized of pipeline.npz: bit-exact in float64, the float32 series = its float32 cast), the
+    reference's fix-up rules on degenerate columns, chunk folding, and the streamed from_arrays front end."""
+    from oracle import timeband_oracle as O
+    from timeband_amd import ops, synthetic
+    from timeband_amd.dataset import TIMEBANDDataset
+    from timeband_amd.utils.logger import NullLogger
+    z, ds = world["z"], world["ds"]
+    V, To, Tf, H, L, B, N = world["dims"]
+    dev = torch.device("cuda", 0)
+    assert np.array_equal(ds.series_dev.cpu().numpy(), z["ds.normalized"].astype(np.float32))
+    np.testing.assert_array_equal(ds.forecast_dev.cpu().numpy(), ds.forecast.numpy())
+    # degenerate columns: constant -> max + 1; all -inf -> min = max (dataset.py:311-312); NaN skipped
+    rng = np.random.default_rng(2)
+    a = rng.normal(size=(1000, 70))
+    a[:, 3] = 2.5
+    a[:, 7] = -np.inf
+    a[5, 9] = np.nan
+    t = torch.from_numpy(a).to(dev)
+    mn, mx = ops.minmax(t)
+    wmn, wmx = O.minmax_info(a, 1.0)
+    np.testing.assert_array_equal(mn.cpu().numpy(), wmn)
+    np.testing.assert_array_equal(mx.cpu().numpy(), wmx)
+    # folded over row chunks == in one go
+    m1, x1 = ops.minmax(t[:300], finish=False)
+    m1, x1 = ops.minmax(t[300:777], m1, x1, finish=False)
+    m1, x1 = ops.minmax(t[777:], m1, x1, finish=True)
+    assert torch.equal(m1, mn) and torch.equal(x1, mx)
+    # from_arrays with tiny chunks == oracle SeriesData
+    values = synthetic.make_series(300, 5, seed=9)
+    values[:40, 2] = np.nan
+    tfeat = synthetic.time_features(300 + Tf)
+    old = TIMEBANDDataset.CHUNK_ROWS
+    TIMEBANDDataset.CHUNK_ROWS = 64
+    try:
+        d2 = TIMEBANDDataset.from_arrays(values, tfeat, dict(logger=NullLogger(), device=dev, batch_size=8, observed_len=To,
+                                                             forecast_len=Tf, stride=1, split_rate=0.8,
+                                                             min_valid_scale=2, sliding_step=0, directory="", data_name="x"))
+    finally:
+        TIMEBANDDataset.CHUNK_ROWS = old
+    s = O.SeriesData(values, tfeat, To, Tf, 0.8)
+    assert np.array_equal(d2.series_dev.cpu().numpy(), s.norm.astype(np.float32))
+    np.testing.assert_array_equal(d2.forecast_dev.cpu().numpy(), s.forecast)
+    np.testing.assert_array_equal(d2.observed_dev.cpu().numpy(), s.observed)
+    np.testing.assert_array_equal(d2.missing_dev.cpu().numpy(), s.missing)
+    np.testing.assert_array_equal(d2.decode_min.numpy(), s.decode_min)
+    np.testing.assert_array_equal(d2.decode_max.numpy(), s.decode_max)
+    # prepare_dataset(_from): windows of the sub-frame data[_from:] (reference dataset.py:160-166)
+    sub = d2.prepare_dataset(_from=17, split=False)
+    enc, dec = O.windowing(s.norm[17:], s.target_cols, To, Tf)
+    assert len(sub) == len(enc)
+    got = sub.gather(3, 4)
+    assert np.array_equal(got["encoded"].cpu().numpy(), enc[3:7]) and np.array_equal(got["decoded"].cpu().numpy(), dec[3:7])
+
+
 def test_initial_weights_match_reference(world):
     z, m = world["z"], world["models"]
     for tag, net in (("init.netD", m.netD), ("init.netG", m.netG)):

@@ -52,6 +52,10 @@ SIGNATURES = {
     "tb_recon_loss_grad": (I, [P, P, L, D, D, P, F, F, F, P, P, I, P]),
     "tb_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),
     "tb_rmsprop_step": (I, [P, P, P, L, D, D, D, I, P]),
+    "tb_minmax_workspace_bytes": (Z, [I]),
+    "tb_minmax": (I, [P, L, I, P, P, I, I, P, Z, P]),
+    "tb_normalize": (I, [P, L, I, P, P, P, P, P]),
+    "tb_take_columns": (I, [P, L, I, P, I, P, P]),
     "tb_window_gather": (I, [P, L, I, P, L, L, I, I, I, P, I, P, P, P]),
     "tb_denormalize": (I, [P, L, I, P, P, P, P]),
     "tb_band_update": (I, [P, I, I, I, P, I, P, P, P, D, P, P, P, P, P]),

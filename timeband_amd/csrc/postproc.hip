@@ -65,6 +65,83 @@ __global__ void denorm_kernel(const float* __restrict__ x, long n, int V, const 
   }
 }
 
+// ---- min-max statistics and normalisation (dataset.py:297-321, :216-227) --------------------------------
+// Column min / max over the rows of a row-major fp64 matrix.  Block (x, y): row slice x, columns [64y, 64y+64);
+// the 256 threads are 4 row lanes x 64 columns, so a wave reads 64 consecutive doubles of a row.  NaNs are
+// skipped (pandas' min/max).  Partials [slice][2][E], then one thread per column folds them in a fixed order.
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const double* __restrict__ data, long rows, int E,
+                                                             double* __restrict__ part) {
+  __shared__ double smn[256], smx[256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + tx;
+  const long per = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  double mn = __builtin_inf(), mx = -__builtin_inf();
+  if (c < E)
+    for (long r = r0 + ty; r < r1; r += 4) {
+      const double v = data[r * E + c];
+      if (v < mn) mn = v;     // false for NaN
+      if (v > mx) mx = v;
+    }
+  smn[threadIdx.x] = mn;
+  smx[threadIdx.x] = mx;
+  __syncthreads();
+  if (ty == 0 && c < E) {
+    for (int k = 1; k < 4; ++k) {
+      mn = fmin(mn, smn[k * 64 + tx]);
+      mx = fmax(mx, smx[k * 64 + tx]);
+    }
+    part[((size_t)blockIdx.x * 2) * E + c] = mn;
+    part[((size_t)blockIdx.x * 2 + 1) * E + c] = mx;
+  }
+}
+
+__global__ void minmax_fold_kernel(const double* __restrict__ part, int nparts, int E, double* mn, double* mx, int init) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  double a = init ? __builtin_inf() : mn[c], b = init ? -__builtin_inf() : mx[c];
+  for (int p = 0; p < nparts; ++p) {
+    a = fmin(a, part[((size_t)p * 2) * E + c]);
+    b = fmax(b, part[((size_t)p * 2 + 1) * E + c]);
+  }
+  mn[c] = a;
+  mx[c] = b;
+}
+
+// the reference's two fix-ups, in its order: min == -inf -> max; then min == max -> max + 1 (dataset.py:311-312)
+__global__ void minmax_finish_kernel(double* mn, double* mx, int E) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  double a = mn[c], b = mx[c];
+  if (a == -__builtin_inf()) a = b;
+  if (a == b) b = b + 1.0;
+  mn[c] = a;
+  mx[c] = b;
+}
+
+// 2 * ((x - min) / (max - min)) - 1 in fp64, numpy's operation order; fp32 series (what every window is cast to,
+// utils/dataset.py:19-20) and, optionally, the fp64 frame (the reference's normalized.csv artefact)
+__global__ void normalize_kernel(const double* __restrict__ data, long n, int E, const double* __restrict__ mn,
+                                 const double* __restrict__ mx, float* __restrict__ out32, double* __restrict__ out64) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % E);
+    const double q = (data[i] - mn[c]) / (mx[c] - mn[c]);
+    const double v = 2.0 * q - 1.0;
+    if (out32) out32[i] = (float)v;
+    if (out64) out64[i] = v;
+  }
+}
+
+// out[r][j] = data[r][cols[j]] : the target columns of the raw frame (dataset.py:130-133 observed / forecast)
+__global__ void take_columns_kernel(const double* __restrict__ data, long rows, int E, const int* __restrict__ cols, int V,
+                                    double* __restrict__ out) {
+  const long n = rows * V;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / V;
+    out[i] = data[r * E + cols[(int)(i - r * V)]];
+  }
+}
+
 // ---- K6 band -------------------------------------------------------------------------------
 // One wave per (row r, variable v).  Row r (time offset from the batch's first forecast step)
 // collects the predictions made for it at every horizon f by window w = r - f: from this batch
@@ -579,6 +656,54 @@ int tb_metrics(const double* tru, const double* pred, const int* mask, long n, d
   if (!tru || !pred || !mask || !out) return tb_set_error(TB_ERR_ARG, "metrics: null pointer");
   hipLaunchKernelGGL(metric_kernel, dim3(1), dim3(256), 0, s, tru, pred, mask, n, 1e-7, out, running);
   TB_LAUNCH_CHECK("metric_kernel");
+  return TB_OK;
+}
+
+constexpr int kMinmaxParts = 512;
+
+size_t tb_minmax_workspace_bytes(int E) { return (size_t)kMinmaxParts * 2 * E * sizeof(double) + 256; }
+
+// Column min / max of data (rows, E) fp64, NaN skipped.  init != 0: start from +-inf; init == 0: fold into what
+// mn / mx hold (a series streamed in row chunks).  finish != 0: apply the reference's fix-ups afterwards.
+int tb_minmax(const double* data, long rows, int E, double* mn, double* mx, int init, int finish, void* ws,
+              size_t ws_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (E <= 0) return TB_OK;
+  if (!mn || !mx || (rows > 0 && (!data || !ws))) return tb_set_error(TB_ERR_ARG, "minmax: null pointer");
+  if (rows > 0) {
+    if (ws_bytes < tb_minmax_workspace_bytes(E)) return tb_set_error(TB_ERR_WORKSPACE, "minmax: workspace too small");
+    long parts = rows / 256;
+    if (parts > kMinmaxParts) parts = kMinmaxParts;
+    if (parts < 1) parts = 1;
+    double* part = static_cast<double*>(ws);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3((int)parts, (E + 63) / 64), dim3(256), 0, s, data, rows, E, part);
+    TB_LAUNCH_CHECK("minmax_partial_kernel");
+    hipLaunchKernelGGL(minmax_fold_kernel, dim3((E + 63) / 64), dim3(64), 0, s, part, (int)parts, E, mn, mx, init);
+    TB_LAUNCH_CHECK("minmax_fold_kernel");
+  }
+  if (finish) {
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3((E + 63) / 64), dim3(64), 0, s, mn, mx, E);
+    TB_LAUNCH_CHECK("minmax_finish_kernel");
+  }
+  return TB_OK;
+}
+
+int tb_normalize(const double* data, long rows, int E, const double* mn, const double* mx, float* out32, double* out64,
+                 void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows <= 0 || E <= 0) return TB_OK;
+  if (!data || !mn || !mx || (!out32 && !out64)) return tb_set_error(TB_ERR_ARG, "normalize: null pointer");
+  hipLaunchKernelGGL(normalize_kernel, dim3(grid_for(rows * E, 16384)), dim3(256), 0, s, data, rows * E, E, mn, mx, out32, out64);
+  TB_LAUNCH_CHECK("normalize_kernel");
+  return TB_OK;
+}
+
+int tb_take_columns(const double* data, long rows, int E, const int* cols, int V, double* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows <= 0 || V <= 0) return TB_OK;
+  if (!data || !cols || !out) return tb_set_error(TB_ERR_ARG, "take_columns: null pointer");
+  hipLaunchKernelGGL(take_columns_kernel, dim3(grid_for(rows * V, 16384)), dim3(256), 0, s, data, rows, E, cols, V, out);
+  TB_LAUNCH_CHECK("take_columns_kernel");
   return TB_OK;
 }
 

@@ -26,8 +26,9 @@ class WindowSet:
     """A contiguous range of sliding windows [w0, w0+length) over the device-resident series.
     Window w starts (first forecast row) at series row i = To + w*stride (dataset.py:208-210)."""
 
-    def __init__(self, ds, w0, length):
-        self.ds, self.w0, self.length = ds, int(w0), int(length)
+    def __init__(self, ds, w0, length, row0=0):
+        """row0: first series row of the sub-frame the windows are cut from (prepare_dataset's `_from`)."""
+        self.ds, self.w0, self.length, self.row0 = ds, int(w0), int(length), int(row0)
 
     def __len__(self):
         return self.length
@@ -41,7 +42,7 @@ class WindowSet:
         d = self.ds
         if start < 0 or count < 0 or start + count > self.length:
             raise IndexError("window range out of bounds")
-        first = d.observed_len + (self.w0 + start) * d.stride
+        first = self.row0 + d.observed_len + (self.w0 + start) * d.stride
         enc, dec = ops.window_gather(d.series_dev, d.tcols_dev, first, count, d.observed_len, d.forecast_len,
                                      stride=d.stride)
         return {"encoded": enc, "decoded": dec}
@@ -148,84 +149,125 @@ class TIMEBANDDataset:
         return raw.set_index(self.time_index).reindex(full).rename_axis(self.time_index).reset_index()
 
     def load_dataset(self, datapath: str = None):
-        """reference dataset.py:117-158, then the device upload."""
+        """reference dataset.py:117-158.  csv parsing and the ffill / bfill stay in pandas (host I/O); the min-max
+        statistics and the normalisation run on the device (tb_minmax, tb_normalize) on the uploaded frame."""
         import pandas as pd
         datapath = self.datapath if datapath is None else datapath
         data = pd.read_csv(datapath, parse_dates=[self.time_index]).set_index(self.time_index)
         data = data.ffill().bfill().fillna(0)                       # dataset.py:111-115
-        To, Tf = self.observed_len, self.forecast_len
-        tgt = data[self.targets]
-        self.observed = torch.from_numpy(tgt[: To + Tf - 1].to_numpy(dtype=np.float64).copy())
-        self.forecast = torch.from_numpy(tgt[To:].to_numpy(dtype=np.float64).copy())
+        To = self.observed_len
         self.missing = pd.read_csv(self.missing_path)[self.targets][To:].to_numpy()
         self.anomaly = pd.read_csv(self.anomaly_path)[self.targets][To:].to_numpy()
-        mn, mx = self.minmax_info(data)
-        norm = 2 * ((data - mn) / (mx - mn)) - 1                    # dataset.py:216-227
-        norm.to_csv(self.normalized_path)
-        pd.DataFrame({"min": mn, "max": mx}).to_csv(self.minmax_path)
-        self.decode_min = torch.tensor(mn[self.targets].to_numpy(dtype=np.float64))
-        self.decode_max = torch.tensor(mx[self.targets].to_numpy(dtype=np.float64))
         self.times = data.index.strftime(self.time_format).tolist()
         cols = list(data.columns)
-        self._finish(norm.to_numpy(dtype=np.float64), [cols.index(c) for c in self.targets])
+        self._check_device()
+        raw = torch.from_numpy(np.ascontiguousarray(data.to_numpy(dtype=np.float64))).to(self.device)
+        norm64 = self._device_state(raw, [cols.index(c) for c in self.targets], want64=True)
+        self.missing_dev = torch.tensor(np.ascontiguousarray(self.missing), dtype=torch.int32, device=self.device).contiguous()
+        # the reference's artefacts (dataset.py:62-66), written from the device results
+        mn, mx = self._mn.cpu().numpy(), self._mx.cpu().numpy()
+        norm = pd.DataFrame(norm64.cpu().numpy(), columns=data.columns, index=data.index)
+        norm.to_csv(self.normalized_path)
+        pd.DataFrame({"min": pd.Series(mn, index=data.columns), "max": pd.Series(mx, index=data.columns)}).to_csv(self.minmax_path)
         return norm
 
     def minmax_info(self, data):
-        """reference dataset.py:297-321."""
-        k = int(len(data) * self.split_rate)
-        mn, mx = data[:k].min(), data[:k].max()
-        mn[mn == -np.inf] = mx
-        mx[mn == mx] = mx + 1
-        return mn, mx
+        """reference dataset.py:297-321 on a (rows, E) float64 device frame -> (min, max) device vectors."""
+        k = int(data.shape[0] * self.split_rate)
+        return ops.minmax(data[:k])
 
     # ------------------------------------------------------------------ device state
-    def _finish(self, norm64, target_cols):
-        dev = self.device
-        if torch.device(dev).type != "cuda":
+    def _check_device(self):
+        if torch.device(self.device).type != "cuda":
             raise RuntimeError("TIMEBANDDataset keeps the series in HBM: config['device'] must be a GPU")
-        self.data_length = norm64.shape[0]
-        self.encode_dim = norm64.shape[1]
-        self.decode_dim = len(target_cols)
+
+    def _device_state(self, raw, target_cols, want64=False):
+        """From the interpolated float64 frame in HBM: min-max over the first split_rate rows, the float32
+        normalised series, the raw target columns (observed / forecast) and the decode range.  The host copies
+        the reference exposes (observed, forecast, decode_min / decode_max) are made only for frames small
+        enough to be worth a host tensor (the 10M x 512 case keeps everything on the device)."""
+        To, Tf = self.observed_len, self.forecast_len
+        R, E = raw.shape
+        self.data_length, self.encode_dim, self.decode_dim = R, E, len(target_cols)
         self.dims = {"encode": self.encode_dim, "decode": self.decode_dim}
-        self.encode_shape = (self.batch_size, self.observed_len, self.encode_dim)
-        self.decode_shape = (self.batch_size, self.forecast_len, self.decode_dim)
-        # the reference casts each float64 window to float32 (utils/dataset.py:19-20): same values
-        self.series_dev = torch.tensor(np.ascontiguousarray(norm64), dtype=torch.float64).to(torch.float32).to(dev).contiguous()
-        self.tcols_dev = torch.tensor(target_cols, dtype=torch.int32, device=dev)
-        self.forecast_dev = self.forecast.to(dev).contiguous()
-        self.observed_dev = self.observed.to(dev).contiguous()
-        self.missing_dev = torch.tensor(np.ascontiguousarray(self.missing), dtype=torch.int32, device=dev).contiguous()
-        self.dmin_dev, self.dmax_dev = self.decode_min.to(dev).contiguous(), self.decode_max.to(dev).contiguous()
+        self.encode_shape = (self.batch_size, To, self.encode_dim)
+        self.decode_shape = (self.batch_size, Tf, self.decode_dim)
+        self.tcols_dev = torch.tensor(target_cols, dtype=torch.int32, device=raw.device)
+        self._mn, self._mx = self.minmax_info(raw)
+        res = ops.normalize(raw, self._mn, self._mx, want64=want64)
+        self.series_dev, norm64 = res if want64 else (res, None)
+        self.forecast_dev = ops.take_columns(raw[To:], self.tcols_dev)
+        self.observed_dev = ops.take_columns(raw[: To + Tf - 1], self.tcols_dev)
+        idx = self.tcols_dev.long()
+        self.dmin_dev, self.dmax_dev = self._mn[idx].contiguous(), self._mx[idx].contiguous()
+        self.decode_min, self.decode_max = self.dmin_dev.cpu(), self.dmax_dev.cpu()
+        self.observed = self.observed_dev.cpu()
+        self.forecast = self.forecast_dev.cpu() if R * self.decode_dim <= self.HOST_COPY_LIMIT else None
+        return norm64
+
+    HOST_COPY_LIMIT = 1 << 26       # elements: above it no host mirror of forecast / missing is kept
+    CHUNK_ROWS = 1 << 18            # from_arrays: rows interpolated on the host and uploaded at a time
 
     @classmethod
     def from_arrays(cls, values, tfeat, config: dict, target_cols=None):
         """Build the dataset from raw arrays without csv / pandas: `values` (N,V) with NaN = missing,
         `tfeat` (N+forecast_len, n_time) time features in final column order.  Same arithmetic as
-        init_dataset + load_dataset; used by bench.py and the large-size tests."""
+        init_dataset + load_dataset; used by bench.py and the large-size tests.  The frame is streamed in
+        row chunks: forward / backward fill on the host with a carry row, the chunk goes up as float64, and
+        everything after that (min-max, normalisation, target columns, missing mask) is device work -- the wide
+        case (512 variables x 10M rows) never holds a second host copy of the frame."""
         self = cls.__new__(cls)
         self.logger = config["logger"]
         self.__dict__ = {**config, **self.__dict__}
         self.stride = int(getattr(self, "stride", 1))
+        self._check_device()
+        dev = self.device
         To, Tf = self.observed_len, self.forecast_len
         N, V = values.shape
-        frame = np.concatenate([tfeat, np.concatenate([values, np.full((Tf, V), np.nan)], 0)], axis=1)
         nt = tfeat.shape[1]
+        R, E = N + Tf, nt + V
         tc = (np.arange(V) if target_cols is None else np.asarray(target_cols)) + nt
-        miss = np.isnan(frame)
-        data = _interpolate(frame)
-        k = int(len(data) * self.split_rate)
-        mn, mx = data[:k].min(0), data[:k].max(0)
-        mn = np.where(mn == -np.inf, mx, mn)
-        mx = np.where(mn == mx, mx + 1, mx)
-        norm = 2 * ((data - mn) / (mx - mn)) - 1
-        self.observed = torch.from_numpy(data[: To + Tf - 1][:, tc].copy())
-        self.forecast = torch.from_numpy(data[To:][:, tc].copy())
-        self.missing = miss[To:][:, tc].astype(np.int64)
-        self.anomaly = np.zeros_like(self.missing)
-        self.decode_min, self.decode_max = torch.tensor(mn[tc]), torch.tensor(mx[tc])
+        # bfill value of each column = its first valid value (0 if there is none): the carry the forward fill starts from
+        carry = np.full(V, np.nan)
+        for r0 in range(0, N, self.CHUNK_ROWS):
+            blk = values[r0:r0 + self.CHUNK_ROWS]
+            need = np.isnan(carry)
+            if not need.any():
+                break
+            ok = ~np.isnan(blk[:, need])
+            first = np.argmax(ok, axis=0)
+            got = ok[first, np.arange(first.size)]
+            vals = blk[:, need][first, np.arange(first.size)]
+            sub = carry[need]
+            sub[got] = vals[got]
+            carry[need] = sub
+        carry = np.where(np.isnan(carry), 0.0, carry)
+        raw = torch.empty(R, E, dtype=torch.float64, device=dev)
+        miss_dev = torch.empty(R - To, len(tc), dtype=torch.int32, device=dev)
+        keep_host = R * len(tc) <= self.HOST_COPY_LIMIT
+        miss_host = np.empty((R - To, len(tc)), np.int64) if keep_host else None
+        for r0 in range(0, R, self.CHUNK_ROWS):
+            r1 = min(R, r0 + self.CHUNK_ROWS)
+            blk = np.full((r1 - r0, V), np.nan)
+            if r0 < N:
+                blk[: min(r1, N) - r0] = values[r0:min(r1, N)]
+            miss = np.isnan(blk)
+            filled, carry = _ffill_chunk(blk, carry)
+            frame = np.concatenate([np.asarray(tfeat[r0:r1], np.float64), filled], axis=1)
+            raw[r0:r1].copy_(torch.from_numpy(frame), non_blocking=False)
+            lo = max(r0, To)
+            if r1 > lo:
+                m = miss[lo - r0:, tc - nt]
+                miss_dev[lo - To:r1 - To].copy_(torch.from_numpy(m.astype(np.int32)))
+                if keep_host:
+                    miss_host[lo - To:r1 - To] = m
+        self.missing_dev = miss_dev
+        self.missing = miss_host
+        self.anomaly = np.zeros_like(miss_host) if keep_host else None
+        self._device_state(raw, list(tc))
+        del raw
         self.targets = [f"v{i}" for i in range(len(tc))]
         self.times = None
-        self._finish(norm, list(tc))
         self.data = None
         return self
 
@@ -237,19 +279,21 @@ class TIMEBANDDataset:
 
     def prepare_dataset(self, _from: int = 0, k_step: int = 0, split=True):
         """reference dataset.py:160-197; returns WindowSet(s) instead of materialised arrays."""
-        if _from != 0:
-            raise NotImplementedError("_from != 0 is never used by the reference's callers")
-        data_len = self.data_length - getattr(self, "sliding_step", 0) + k_step
+        _from = int(_from)
+        if _from < 0:
+            _from += self.data_length
+        sliding_len = self.data_length - getattr(self, "sliding_step", 0) + k_step
+        data_len = max(0, min(sliding_len, self.data_length) - _from)       # len(self.data[_from:sliding_len])
         nwin = self.n_windows(data_len)
         if not split:
-            full = WindowSet(self, 0, nwin)
+            full = WindowSet(self, 0, nwin, _from)
             self.logger.info(f" - Data shape : {full.shape()}")
             return full
         valid_minlen = int(self.min_valid_scale * self.forecast_len)
         valid_idx = min(int(data_len * self.split_rate), data_len - valid_minlen)
         split_idx = max(0, min(nwin, valid_idx - self.forecast_len - self.observed_len))
-        self.trainset = WindowSet(self, 0, split_idx)
-        validset = WindowSet(self, split_idx, nwin - split_idx)
+        self.trainset = WindowSet(self, 0, split_idx, _from)
+        validset = WindowSet(self, split_idx, nwin - split_idx, _from)
         self.logger.info(f"- Train shape: {self.trainset.shape()} Valid shape: {validset.shape()}")
         return self.trainset, validset
 
@@ -265,6 +309,18 @@ class TIMEBANDDataset:
         if not hasattr(self, "decode_max") or not hasattr(self, "decode_min"):
             raise Exception("Try to denormalize, but the input was not normalized")
         return ops.denormalize(data, self.dmin_dev, self.dmax_dev)
+
+
+def _ffill_chunk(a, carry):
+    """Forward fill of one row chunk (float64, NaN = missing) starting from `carry` (the last valid value of
+    every column before the chunk, or the column's first valid value / 0 at the very start: that is the
+    backward fill and the final fillna(0) of reference dataset.py:111-115).  Returns (filled, new carry)."""
+    a = np.concatenate([carry[None], np.asarray(a, np.float64)], axis=0)
+    n = a.shape[0]
+    idx = np.where(~np.isnan(a), np.arange(n)[:, None], 0)
+    np.maximum.accumulate(idx, axis=0, out=idx)
+    filled = np.take_along_axis(a, idx, axis=0)
+    return filled[1:], filled[-1].copy()
 
 
 def _interpolate(a):

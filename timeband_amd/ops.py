@@ -461,6 +461,48 @@ def window_gather(series, target_cols, first, nwin, To, Tf, stride=1, starts=Non
     return enc, dec
 
 
+def minmax(data, mn=None, mx=None, finish=True):
+    """Column min / max of a float64 (rows, E) device frame; mn / mx given: fold this chunk into them."""
+    _need_cuda(data)
+    data = _c(data, torch.float64)
+    rows, E = data.shape
+    init = mn is None
+    if init:
+        mn = torch.empty(E, dtype=torch.float64, device=data.device)
+        mx = torch.empty(E, dtype=torch.float64, device=data.device)
+    rt = Runtime.get(data.device)
+    ws = rt.workspace(_lib.load().tb_minmax_workspace_bytes(E))
+    _lib.call("tb_minmax", _ptr(data), rows, E, _ptr(mn), _ptr(mx), int(init), int(finish), _ptr(ws), ws.numel(), _stream())
+    return mn, mx
+
+
+def normalize(data, mn, mx, out32=None, want64=False):
+    """2*((x-min)/(max-min))-1 of a float64 (rows, E) device frame -> float32 series (and the float64 frame)."""
+    _need_cuda(data, mn, mx)
+    data, mn, mx = _c(data, torch.float64), _c(mn, torch.float64), _c(mx, torch.float64)
+    rows, E = data.shape
+    if out32 is None:
+        out32 = torch.empty(rows, E, dtype=torch.float32, device=data.device)
+    elif out32.shape != (rows, E) or out32.dtype != torch.float32 or not out32.is_contiguous():
+        raise RuntimeError("normalize: out32 must be contiguous float32 (rows, E)")
+    out64 = torch.empty(rows, E, dtype=torch.float64, device=data.device) if want64 else None
+    _lib.call("tb_normalize", _ptr(data), rows, E, _ptr(mn), _ptr(mx), _ptr(out32), _ptr(out64), _stream())
+    return (out32, out64) if want64 else out32
+
+
+def take_columns(data, cols, out=None):
+    _need_cuda(data, cols)
+    data = _c(data, torch.float64)
+    if cols.dtype != torch.int32:
+        raise RuntimeError("take_columns: cols must be int32")
+    rows, E = data.shape
+    V = cols.numel()
+    if out is None:
+        out = torch.empty(rows, V, dtype=torch.float64, device=data.device)
+    _lib.call("tb_take_columns", _ptr(data), rows, E, _ptr(cols), V, _ptr(out), _stream())
+    return out
+
+
 def denormalize(x, dmin, dmax):
     _need_cuda(x, dmin, dmax)
     x, dmin, dmax = _f32c(x), _c(dmin, torch.float64), _c(dmax, torch.float64)
