@@ -35,6 +35,10 @@ CONFIGS = {
     "cfg2": dict(V=32, NT=4, To=128, Tf=128, H=256, L=1, B=512, N=100000),
     # BASELINE.json configs[3], long context (not the headline; the critic batch is forecast_len = 1024 windows)
     "cfg4": dict(V=32, NT=4, To=1024, Tf=1024, H=512, L=2, B=64, N=12000),
+    # BASELINE.json configs[4], wide multivariate cleaning (cleaner path only: no training step).  A step = one launch
+    # of B windows: gather -> G forward -> band -> adjust.  --rows sets the series length (10M in BASELINE.json;
+    # the default keeps the run short)
+    "cfg5": dict(V=512, NT=4, To=48, Tf=48, H=64, L=1, B=8192, N=1000000, mode="clean"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -104,12 +108,93 @@ def build(cfg, device, seed=31):
     return ds, trainset, trainer
 
 
+def run_clean(args, cfg, device):
+    """cfg5: the cleaning / imputation pass (reference source/cleaner.py:55-128) over a device-resident series."""
+    from timeband_amd import _lib, ops, synthetic
+    from timeband_amd.dataset import TIMEBANDDataset
+    from timeband_amd.model import TIMEBANDModel
+    from timeband_amd.postprocess import BandAdjust
+    from timeband_amd.utils.initiate import seeding
+    from timeband_amd.utils.lstm_layer import LSTMGenerator
+    V, To, Tf, H, L, B = (cfg[k] for k in ("V", "To", "Tf", "H", "L", "B"))
+    N = args.rows or cfg["N"]
+    seeding(31)
+    lib = _lib.load()
+    core = dict(logger=_Log(), device=device, batch_size=B, observed_len=To, forecast_len=Tf, directory="", data_name="synthetic")
+    t0 = time.perf_counter()
+    ds = TIMEBANDDataset.from_arrays(synthetic.LazySeries(N, V, 31, device), synthetic.LazyTimeFeatures(N + Tf),
+                                     {**core, "stride": 1, "split_rate": 0.9, "min_valid_scale": 2, "sliding_step": 0})
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t0
+    netG = LSTMGenerator(V + cfg["NT"], V, To, Tf, H, L, device).to(device)
+    full = ds.prepare_dataset(split=False)
+    nlaunch = len(full) // B
+    if nlaunch < 1:
+        raise SystemExit("series too short for one launch")
+    post = BandAdjust(ds, "cleaner", 1.0, 0.2, 0.3, keep_outputs=True)
+    state = {"i": 0}
+
+    def step():
+        if state["i"] == nlaunch:
+            state["i"] = 0
+            post.reset()
+        batch = full.gather(state["i"] * B, B)
+        state["i"] += 1
+        with torch.no_grad():
+            post.step(netG(batch["encoded"])[:, :Tf])
+
+    kids = {"lstm_fwd": _lib.K_LSTM_FWD, "gemm": _lib.K_GEMM, "band": _lib.K_BAND, "gather": _lib.K_GATHER}
+
+    def read(k):
+        n, ms, by = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+        lib.tb_prof_read(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by))
+        lib.tb_prof_enable(k, 0)
+        return dict(launches=n.value, total_ms=ms.value, algo_bytes=by.value)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ops.check_errors(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.check_errors(device)
+    extra = min(5, args.steps)
+    for k in kids.values():
+        lib.tb_prof_enable(k, 1)
+    for _ in range(extra):
+        step()
+    torch.cuda.synchronize()
+    prof = {name: read(k) for name, k in kids.items()}
+    E = V + cfg["NT"]
+    # SURVEY.md 8(d), clean path: 4 * sum over LSTM layers of To * (in + h) bytes per window
+    abw = 4 * To * sum(i + h for i, h in ((E, H // 4), (H // 4, H // 2), (H // 2, H))) * L
+    value = B * args.steps / dt
+    dom = max(prof, key=lambda k: prof[k]["total_ms"])
+    out = {"metric": "cleaning windows/sec", "value": round(value, 1), "unit": "windows/s", "n_gpus": 1, "rccl_ranks": 0,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "rows_per_s": round(value, 1),
+           "config": {"workload": f"cfg5: cleaning pass (window gather + G forward + band + adjust), V={V} E={E} window={To} "
+                                  f"hidden={H} {B} windows/launch, series of {N} rows resident in HBM",
+                      "series_rows": N, "windows": len(full), "dataset_setup_s": round(setup_s, 2)},
+           "roofline": {"bound": "hbm", "kernel": "whole cleaning launch (all kernels of one step)",
+                        "achieved": round(abw * value / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(abw * value / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algo_bytes_per_window": abw, "dominant_family": dom},
+           "kernel_ms_per_step": {k: round(v["total_ms"] / max(1, extra), 4) for k, v in prof.items()}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0, help="series length (cfg5; default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full", action="store_true", help="also time band/adjust/scores inside the step")
     ap.add_argument("--share-gpass", action="store_true",
@@ -147,6 +232,10 @@ def main():
         assert dist.get_world_size() == args.gpus
 
     cfg = CONFIGS[args.config]
+    if cfg.get("mode") == "clean":
+        if world > 1:
+            raise SystemExit("cfg5 (cleaning) is a single-GPU measurement here")
+        return run_clean(args, cfg, device)
     ds, trainset, trainer = build(cfg, device)
     B = cfg["B"]
     if args.share_gpass:

@@ -149,6 +149,13 @@ int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, doub
  *   series the windows are cut from (utils/dataset.py:19-20 casts every window to float32) and/or the float64
  *   frame of the reference's normalized.csv.
  * tb_take_columns: the target columns of the frame (observed / forecast, source/dataset.py:130-133). */
+/* tb_interpolate: interpolate, source/dataset.py:111-115 -- forward fill, backward fill of the leading gap, 0
+ *   for an empty column, IN PLACE on the float64 frame (rows, E), NaN = missing.  Optionally records the
+ *   missing mask of the target columns from row row_off on (missing_label.csv, dataset.py:94-103,133):
+ *   tpos (E) int32 = position of a column among the V targets or -1, missing (rows-row_off, V) int32. */
+size_t tb_interpolate_workspace_bytes(long rows, int E);
+int tb_interpolate(double* data, long rows, int E, const int* tpos, int V, long row_off, int* missing, void* ws,
+                   size_t ws_bytes, void* stream);
 size_t tb_minmax_workspace_bytes(int E);
 int tb_minmax(const double* data, long rows, int E, double* mn, double* mx, int init, int finish, void* ws,
               size_t ws_bytes, void* stream);

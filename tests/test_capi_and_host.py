@@ -65,39 +65,13 @@ def test_cpu_tensor_is_rejected_loudly():
         ops.linear_act(torch.zeros(4, 4), torch.zeros(2, 4), None)
 
 
-def test_interpolate_and_window_math_match_oracle():
+def test_window_math_matches_oracle():
     from oracle import timeband_oracle as O
-    from timeband_amd.dataset import _interpolate, TIMEBANDDataset
-    rng = np.random.default_rng(0)
-    a = rng.normal(size=(50, 4))
-    a[rng.random((50, 4)) < 0.3] = np.nan
-    a[:3, 0] = np.nan          # leading gap -> backward fill
-    a[:, 3] = np.nan           # empty column -> zeros
-    np.testing.assert_array_equal(_interpolate(a), O.interpolate(a))
+    from timeband_amd.dataset import TIMEBANDDataset
     ds = TIMEBANDDataset.__new__(TIMEBANDDataset)
     for n, To, Tf, stride in ((172, 24, 12, 1), (100, 10, 3, 1), (100, 10, 3, 2), (30, 20, 11, 1)):
         ds.observed_len, ds.forecast_len, ds.stride, ds.data_length = To, Tf, stride, n
         assert ds.n_windows() == len(O.window_starts(n, To, Tf, stride))
-
-
-def test_chunked_fill_matches_whole_frame_fill():
-    """from_arrays streams the frame in row chunks: forward fill with a carry row that starts at each column's
-    first valid value == ffill + bfill + fillna(0) over the whole frame (reference dataset.py:111-115)."""
-    from oracle import timeband_oracle as O
-    from timeband_amd.dataset import _ffill_chunk
-    rng = np.random.default_rng(1)
-    a = rng.normal(size=(97, 5))
-    a[rng.random((97, 5)) < 0.4] = np.nan
-    a[:40, 1] = np.nan         # leading gap longer than a chunk
-    a[:, 4] = np.nan           # empty column
-    want = O.interpolate(a)
-    first = np.array([col[~np.isnan(col)][0] if (~np.isnan(col)).any() else 0.0 for col in a.T])
-    for chunk in (7, 32, 200):
-        carry, parts = first.copy(), []
-        for r0 in range(0, len(a), chunk):
-            f, carry = _ffill_chunk(a[r0:r0 + chunk], carry)
-            parts.append(f)
-        np.testing.assert_array_equal(np.concatenate(parts), want)
 
 
 def test_time_feature_order():

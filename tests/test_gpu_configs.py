@@ -176,6 +176,48 @@ def test_cfg4_long_context_two_layer_iteration(dev):
             assert d.max() <= 2.1 * lr, (k_, d.max())
 
 
+def test_cfg4_full_size_properties(dev):
+    """BASELINE.json configs[3] at FULL size (window 1024, hidden 512, 2-layer, batch 64; no oracle at this size):
+    the persistent kernels' rings cycle 341 times per launch and the 32-bit descriptors span T*4H*rows = 268 MB.
+    Finite outputs in range, no wait timeout, bit-exact batch-split invariance of G and D forward, finite
+    gradients of a whole D-phase + G-phase backward, and gradients additive over the batch."""
+    from timeband_amd import ops
+    V, NT, To, Tf, H, L, B = 32, 4, 1024, 1024, 512, 2, 64
+    E = V + NT
+    netD, netG = make_nets(V, E, To, Tf, H, L, dev)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.rand(B, To, E, generator=g) * 2 - 1).to(dev)
+    y = (torch.rand(B, Tf, V, generator=g) * 2 - 1).to(dev)
+    with torch.no_grad():
+        full = netG(x)
+        part = torch.cat([netG(x[:20]), netG(x[20:])], 0)
+        dfull = netD(y)
+        dpart = torch.cat([netD(y[:33]), netD(y[33:])], 0)
+    torch.cuda.synchronize()
+    ops.check_errors()
+    assert torch.equal(full, part) and torch.equal(dfull, dpart)
+    assert torch.isfinite(full).all() and full.abs().max() < 1.0 and (dfull > 0).all() and (dfull < 1).all()
+
+    def grads(xs, ys):
+        for n in (netD, netG):
+            n.zero_grad(set_to_none=True)
+        fake = netG(xs)
+        Dy, DGx = netD.pair(ys, fake)
+        (((Dy - 0.9) ** 2).sum() + ((DGx - 0.1) ** 2).sum() + ((fake - ys) ** 2).sum()).backward()
+        torch.cuda.synchronize()
+        ops.check_errors()
+        return [p.grad.detach().double().clone() for n in (netD, netG) for p in n.parameters()]
+
+    g_all = grads(x, y)
+    assert all(bool(torch.isfinite(t).all()) for t in g_all)
+    g_a, g_b = grads(x[:32], y[:32]), grads(x[32:], y[32:])
+    gmax = max(float(t.abs().max()) for t in g_all)
+    for ga, a, b in zip(g_all, g_a, g_b):
+        assert float((ga - (a + b)).abs().max()) <= 1e-3 * (float(ga.abs().max()) + 0.01 * gmax)
+    for n in (netD, netG):
+        n.zero_grad(set_to_none=True)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_cfg5_wide_cleaning_vs_oracle(dev):
     """BASELINE.json configs[4] (512 variables, detect + impute through the cleaner path) on a 260-row

@@ -104,6 +104,17 @@ def test_device_minmax_normalize_match_reference(world):
     m1, x1 = ops.minmax(t[300:777], m1, x1, finish=False)
     m1, x1 = ops.minmax(t[777:], m1, x1, finish=True)
     assert torch.equal(m1, mn) and torch.equal(x1, mx)
+    # fill kernel: gaps longer than a row block (1024), a leading gap, an empty column; the missing mask
+    b = rng.normal(size=(5000, 6))
+    b[rng.random((5000, 6)) < 0.3] = np.nan
+    b[:1500, 1] = np.nan
+    b[2000:4300, 2] = np.nan
+    b[:, 5] = np.nan
+    tb = torch.from_numpy(b.copy()).to(dev)
+    tpos = torch.tensor([-1, 0, -1, 1, -1, 2], dtype=torch.int32, device=dev)
+    miss = ops.interpolate(tb, tpos, 3, 100)
+    np.testing.assert_array_equal(tb.cpu().numpy(), O.interpolate(b))
+    np.testing.assert_array_equal(miss.cpu().numpy(), np.isnan(b)[100:][:, [1, 3, 5]].astype(np.int32))
     # from_arrays with tiny chunks == oracle SeriesData
     values = synthetic.make_series(300, 5, seed=9)
     values[:40, 2] = np.nan

@@ -142,6 +142,64 @@ __global__ void take_columns_kernel(const double* __restrict__ data, long rows, 
   }
 }
 
+// ---- interpolate: ffill, bfill, 0 (dataset.py:111-115) on the device ------------------------------------
+// A column is a chain along the rows, cut into blocks of FILL_ROWS rows: (A) every (block, column) thread finds the
+// first and the last valid value of its block; (B) one thread per column walks the blocks: the value carried
+// into each block (the column's first valid value for the leading gap -- the backward fill -- or 0 for an empty
+// column); (C) every (block, column) thread fills its rows from the carried value and records which entries
+// were missing.  Consecutive threads are consecutive columns, so every access is a contiguous run of a row.
+constexpr int FILL_ROWS = 1024;
+
+__global__ __launch_bounds__(64) void fill_scan_kernel(const double* __restrict__ data, long rows, int E,
+                                                       double* __restrict__ first, double* __restrict__ last) {
+  const int c = blockIdx.y * 64 + threadIdx.x;
+  if (c >= E) return;
+  const long r0 = (long)blockIdx.x * FILL_ROWS, r1 = r0 + FILL_ROWS < rows ? r0 + FILL_ROWS : rows;
+  double f = __builtin_nan(""), l = __builtin_nan("");
+  bool have = false;
+  for (long r = r0; r < r1; ++r) {
+    const double v = data[r * E + c];
+    if (!isnan(v)) {
+      if (!have) { f = v; have = true; }
+      l = v;
+    }
+  }
+  first[(size_t)blockIdx.x * E + c] = f;
+  last[(size_t)blockIdx.x * E + c] = l;
+}
+
+__global__ void fill_carry_kernel(const double* __restrict__ first, double* __restrict__ last, int nblocks, int E) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= E) return;
+  double carry = 0.0;                       // empty column -> 0
+  for (int b = 0; b < nblocks; ++b) {
+    const double f = first[(size_t)b * E + c];
+    if (!isnan(f)) { carry = f; break; }    // leading gap -> the first valid value (backward fill)
+  }
+  for (int b = 0; b < nblocks; ++b) {       // last[b] becomes the value carried INTO block b
+    const double l = last[(size_t)b * E + c];
+    last[(size_t)b * E + c] = carry;
+    if (!isnan(l)) carry = l;
+  }
+}
+
+__global__ __launch_bounds__(64) void fill_apply_kernel(double* __restrict__ data, long rows, int E,
+                                                        const double* __restrict__ carry_in, const int* __restrict__ tpos,
+                                                        int V, long row_off, int* __restrict__ missing) {
+  const int c = blockIdx.y * 64 + threadIdx.x;
+  if (c >= E) return;
+  const long r0 = (long)blockIdx.x * FILL_ROWS, r1 = r0 + FILL_ROWS < rows ? r0 + FILL_ROWS : rows;
+  double prev = carry_in[(size_t)blockIdx.x * E + c];
+  const int tp = (missing && tpos) ? tpos[c] : -1;
+  for (long r = r0; r < r1; ++r) {
+    const double v = data[r * E + c];
+    const bool miss = isnan(v);
+    if (miss) data[r * E + c] = prev;
+    else prev = v;
+    if (tp >= 0 && r >= row_off) missing[(r - row_off) * V + tp] = miss ? 1 : 0;
+  }
+}
+
 // ---- K6 band -------------------------------------------------------------------------------
 // One wave per (row r, variable v).  Row r (time offset from the batch's first forecast step)
 // collects the predictions made for it at every horizon f by window w = r - f: from this batch
@@ -656,6 +714,36 @@ int tb_metrics(const double* tru, const double* pred, const int* mask, long n, d
   if (!tru || !pred || !mask || !out) return tb_set_error(TB_ERR_ARG, "metrics: null pointer");
   hipLaunchKernelGGL(metric_kernel, dim3(1), dim3(256), 0, s, tru, pred, mask, n, 1e-7, out, running);
   TB_LAUNCH_CHECK("metric_kernel");
+  return TB_OK;
+}
+
+size_t tb_interpolate_workspace_bytes(long rows, int E) {
+  const long nblocks = (rows + FILL_ROWS - 1) / FILL_ROWS;
+  return (size_t)nblocks * 2 * E * sizeof(double) + 256;
+}
+
+// data (rows, E) float64 with NaN = missing, filled IN PLACE: forward fill, backward fill of the leading gap, 0
+// for an empty column (interpolate, source/dataset.py:111-115).  tpos (E) int32, nullable: tpos[c] = position of
+// column c among the V target columns or -1; missing (rows - row_off, V) int32, nullable: 1 where the entry of
+// row r >= row_off, target column c was missing (the reference's missing_label.csv, dataset.py:94-103,133).
+int tb_interpolate(double* data, long rows, int E, const int* tpos, int V, long row_off, int* missing, void* ws,
+                   size_t ws_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows <= 0 || E <= 0) return TB_OK;
+  if (!data || !ws) return tb_set_error(TB_ERR_ARG, "interpolate: null pointer");
+  if (missing && (!tpos || V <= 0 || row_off < 0)) return tb_set_error(TB_ERR_ARG, "interpolate: missing mask needs tpos, V, row_off");
+  if (ws_bytes < tb_interpolate_workspace_bytes(rows, E)) return tb_set_error(TB_ERR_WORKSPACE, "interpolate: workspace too small");
+  const long nblocks = (rows + FILL_ROWS - 1) / FILL_ROWS;
+  if (nblocks > 0x7FFFFFFFl) return tb_set_error(TB_ERR_UNSUPPORTED, "interpolate: too many rows");
+  double* first = static_cast<double*>(ws);
+  double* last = first + (size_t)nblocks * E;
+  const dim3 grid((unsigned)nblocks, (E + 63) / 64);
+  hipLaunchKernelGGL(fill_scan_kernel, grid, dim3(64), 0, s, data, rows, E, first, last);
+  TB_LAUNCH_CHECK("fill_scan_kernel");
+  hipLaunchKernelGGL(fill_carry_kernel, dim3((E + 63) / 64), dim3(64), 0, s, first, last, (int)nblocks, E);
+  TB_LAUNCH_CHECK("fill_carry_kernel");
+  hipLaunchKernelGGL(fill_apply_kernel, grid, dim3(64), 0, s, data, rows, E, last, tpos, V, row_off, missing);
+  TB_LAUNCH_CHECK("fill_apply_kernel");
   return TB_OK;
 }
 

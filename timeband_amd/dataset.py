@@ -212,10 +212,9 @@ class TIMEBANDDataset:
     def from_arrays(cls, values, tfeat, config: dict, target_cols=None):
         """Build the dataset from raw arrays without csv / pandas: `values` (N,V) with NaN = missing,
         `tfeat` (N+forecast_len, n_time) time features in final column order.  Same arithmetic as
-        init_dataset + load_dataset; used by bench.py and the large-size tests.  The frame is streamed in
-        row chunks: forward / backward fill on the host with a carry row, the chunk goes up as float64, and
-        everything after that (min-max, normalisation, target columns, missing mask) is device work -- the wide
-        case (512 variables x 10M rows) never holds a second host copy of the frame."""
+        init_dataset + load_dataset; used by bench.py and the large-size tests.  `values` / `tfeat` only have to
+        support row slicing (numpy arrays, or objects that produce host arrays or device tensors per slice): the
+        frame goes up in row chunks and the wide case (512 variables x 10M rows) never holds a second host copy."""
         self = cls.__new__(cls)
         self.logger = config["logger"]
         self.__dict__ = {**config, **self.__dict__}
@@ -227,43 +226,24 @@ class TIMEBANDDataset:
         nt = tfeat.shape[1]
         R, E = N + Tf, nt + V
         tc = (np.arange(V) if target_cols is None else np.asarray(target_cols)) + nt
-        # bfill value of each column = its first valid value (0 if there is none): the carry the forward fill starts from
-        carry = np.full(V, np.nan)
-        for r0 in range(0, N, self.CHUNK_ROWS):
-            blk = values[r0:r0 + self.CHUNK_ROWS]
-            need = np.isnan(carry)
-            if not need.any():
-                break
-            ok = ~np.isnan(blk[:, need])
-            first = np.argmax(ok, axis=0)
-            got = ok[first, np.arange(first.size)]
-            vals = blk[:, need][first, np.arange(first.size)]
-            sub = carry[need]
-            sub[got] = vals[got]
-            carry[need] = sub
-        carry = np.where(np.isnan(carry), 0.0, carry)
+        # the raw frame goes up in row chunks (host arrays, or device tensors from a device-side generator);
+        # everything after that is device work: fill (tb_interpolate, which also records the missing mask),
+        # min-max, normalisation, target columns
         raw = torch.empty(R, E, dtype=torch.float64, device=dev)
-        miss_dev = torch.empty(R - To, len(tc), dtype=torch.int32, device=dev)
-        keep_host = R * len(tc) <= self.HOST_COPY_LIMIT
-        miss_host = np.empty((R - To, len(tc)), np.int64) if keep_host else None
+        up = lambda a: (a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=torch.float64)
         for r0 in range(0, R, self.CHUNK_ROWS):
             r1 = min(R, r0 + self.CHUNK_ROWS)
-            blk = np.full((r1 - r0, V), np.nan)
+            raw[r0:r1, :nt] = up(tfeat[r0:r1])
             if r0 < N:
-                blk[: min(r1, N) - r0] = values[r0:min(r1, N)]
-            miss = np.isnan(blk)
-            filled, carry = _ffill_chunk(blk, carry)
-            frame = np.concatenate([np.asarray(tfeat[r0:r1], np.float64), filled], axis=1)
-            raw[r0:r1].copy_(torch.from_numpy(frame), non_blocking=False)
-            lo = max(r0, To)
-            if r1 > lo:
-                m = miss[lo - r0:, tc - nt]
-                miss_dev[lo - To:r1 - To].copy_(torch.from_numpy(m.astype(np.int32)))
-                if keep_host:
-                    miss_host[lo - To:r1 - To] = m
-        self.missing_dev = miss_dev
-        self.missing = miss_host
-        self.anomaly = np.zeros_like(miss_host) if keep_host else None
+                raw[r0:min(r1, N), nt:] = up(values[r0:min(r1, N)])
+            if r1 > N:
+                raw[max(r0, N):r1, nt:] = float("nan")          # forecast_len empty rows (dataset.py:262-279)
+        tpos = torch.full((E,), -1, dtype=torch.int32)
+        tpos[torch.as_tensor(tc, dtype=torch.long)] = torch.arange(len(tc), dtype=torch.int32)
+        self.missing_dev = ops.interpolate(raw, tpos.to(dev), len(tc), To)
+        keep_host = R * len(tc) <= self.HOST_COPY_LIMIT
+        self.missing = self.missing_dev.cpu().numpy().astype(np.int64) if keep_host else None
+        self.anomaly = np.zeros_like(self.missing) if keep_host else None
         self._device_state(raw, list(tc))
         del raw
         self.targets = [f"v{i}" for i in range(len(tc))]
@@ -309,34 +289,3 @@ class TIMEBANDDataset:
         if not hasattr(self, "decode_max") or not hasattr(self, "decode_min"):
             raise Exception("Try to denormalize, but the input was not normalized")
         return ops.denormalize(data, self.dmin_dev, self.dmax_dev)
-
-
-def _ffill_chunk(a, carry):
-    """Forward fill of one row chunk (float64, NaN = missing) starting from `carry` (the last valid value of
-    every column before the chunk, or the column's first valid value / 0 at the very start: that is the
-    backward fill and the final fillna(0) of reference dataset.py:111-115).  Returns (filled, new carry)."""
-    a = np.concatenate([carry[None], np.asarray(a, np.float64)], axis=0)
-    n = a.shape[0]
-    idx = np.where(~np.isnan(a), np.arange(n)[:, None], 0)
-    np.maximum.accumulate(idx, axis=0, out=idx)
-    filled = np.take_along_axis(a, idx, axis=0)
-    return filled[1:], filled[-1].copy()
-
-
-def _interpolate(a):
-    """ffill, bfill, then 0 (reference dataset.py:111-115) on a float64 array."""
-    a = np.array(a, np.float64)
-    n = a.shape[0]
-    idx = np.where(~np.isnan(a), np.arange(n)[:, None], -1)
-    np.maximum.accumulate(idx, axis=0, out=idx)
-    filled = np.take_along_axis(a, np.maximum(idx, 0), axis=0)
-    filled[idx < 0] = np.nan
-    # backward fill of the leading NaNs
-    first = np.argmax(~np.isnan(filled), axis=0)
-    for j in range(a.shape[1]):
-        col = filled[:, j]
-        if np.isnan(col).all():
-            col[:] = 0.0
-        else:
-            col[:first[j]] = col[first[j]]
-    return filled

@@ -461,6 +461,25 @@ def window_gather(series, target_cols, first, nwin, To, Tf, stride=1, starts=Non
     return enc, dec
 
 
+def interpolate(data, tpos=None, V=0, row_off=0):
+    """ffill / bfill / 0 of a float64 (rows, E) device frame IN PLACE; returns the int32 missing mask of the target
+    columns for rows >= row_off when `tpos` (E, int32: target position or -1) is given."""
+    _need_cuda(data, tpos)
+    if data.dtype != torch.float64 or not data.is_contiguous():
+        raise RuntimeError("interpolate: data must be contiguous float64")
+    rows, E = data.shape
+    missing = None
+    if tpos is not None:
+        if tpos.dtype != torch.int32 or tpos.numel() != E:
+            raise RuntimeError("interpolate: tpos must be int32 of length E")
+        missing = torch.empty(max(0, rows - row_off), V, dtype=torch.int32, device=data.device)
+    rt = Runtime.get(data.device)
+    ws = rt.workspace(_lib.load().tb_interpolate_workspace_bytes(rows, E))
+    _lib.call("tb_interpolate", _ptr(data), rows, E, _ptr(tpos), int(V), int(row_off), _ptr(missing), _ptr(ws),
+              ws.numel(), _stream())
+    return missing
+
+
 def minmax(data, mn=None, mx=None, finish=True):
     """Column min / max of a float64 (rows, E) device frame; mn / mx given: fold this chunk into them."""
     _need_cuda(data)

@@ -21,10 +21,19 @@ from . import dp, ops
 
 
 class BandAdjust:
-    def __init__(self, dataset, variant, band_width, missing_gamma, anomaly_gamma, keep_outputs=False):
+    def __init__(self, dataset, variant, band_width, missing_gamma, anomaly_gamma, keep_outputs=False, out_dtype=None):
+        """keep_outputs: assemble the whole cleaned series and its bands on the device (clean / predict).
+        out_dtype: their storage type -- float64 like the reference's arrays by default; float32 when three
+        float64 copies of the series would not leave room in HBM (512 variables x 10M rows: 123 GB)."""
         self.ds, self.variant = dataset, variant
         self.w, self.a, self.b = band_width, missing_gamma, anomaly_gamma
         self.keep = keep_outputs
+        if out_dtype is None:
+            dev = dataset.series_dev.device
+            big = dev.type == "cuda" and 3 * dataset.data_length * dataset.decode_dim * 8 > \
+                0.3 * torch.cuda.get_device_properties(dev).total_memory
+            out_dtype = torch.float32 if big else torch.float64
+        self.out_dtype = out_dtype
         self.reset()
 
     def reset(self):
@@ -45,8 +54,9 @@ class BandAdjust:
         self.last_row = None
         if self.keep:
             n0 = d.observed_dev.shape[0]
-            mk = lambda: torch.cat([d.observed_dev, torch.zeros(d.data_length - n0, d.decode_dim,
-                                                                dtype=torch.float64, device=d.observed_dev.device)])
+            mk = lambda: torch.cat([d.observed_dev.to(self.out_dtype),
+                                    torch.zeros(d.data_length - n0, d.decode_dim, dtype=self.out_dtype,
+                                                device=d.observed_dev.device)])
             self.outputs, self.lower_bands, self.upper_bands = mk(), mk(), mk()
 
     def step(self, fake_y, part=None):

@@ -72,3 +72,45 @@ def write_csv(directory: str, data_name: str, length: int, n_vars: int, seed: in
     path = os.path.join(directory, f"{data_name}.csv")
     df.to_csv(path, index=False)
     return path
+
+
+class LazySeries:
+    """The same kind of signal as make_series, generated per ROW SLICE on a device with torch: for series too
+    long to build on the host (512 variables x 10M rows = 41 GB of float64).  Input generation only -- nothing
+    of the product path runs here.  Deterministic per (seed, slice start)."""
+
+    def __init__(self, length, n_vars, seed=31, device="cuda", missing_rate=0.01, spike_rate=0.002):
+        self.shape = (int(length), int(n_vars))
+        self.seed, self.device, self.missing_rate, self.spike_rate = seed, device, missing_rate, spike_rate
+
+    def __getitem__(self, sl):
+        import torch
+        r0, r1, step = sl.indices(self.shape[0])
+        assert step == 1
+        g = torch.Generator(device=self.device).manual_seed(self.seed * 1000003 + r0)
+        t = torch.arange(r0, r1, dtype=torch.float64, device=self.device)[:, None]
+        v = torch.arange(self.shape[1], dtype=torch.float64, device=self.device)[None, :]
+        n = (r1 - r0, self.shape[1])
+        rnd = lambda: torch.rand(n, generator=g, device=self.device)
+        x = (torch.sin(2.0 * np.pi * t / 24.0 * (1.0 + 0.1 * v)) + 0.5 * torch.sin(2.0 * np.pi * t / 168.0 + v)
+             + 0.1 * torch.randn(n, generator=g, device=self.device, dtype=torch.float64))
+        if self.spike_rate > 0:
+            sign = torch.where(rnd() < 0.5, -1.0, 1.0)
+            x = torch.where(rnd() < self.spike_rate, x + 5.0 * 0.8 * sign, x)
+        if self.missing_rate > 0:
+            x = torch.where(rnd() < self.missing_rate, float("nan"), x)
+        return x
+
+
+class LazyTimeFeatures:
+    """hour, weekday, day, month columns of an hourly index with 30-day months (pandas cannot index 10M hours: its
+    timestamps end in 2262), per row slice, on the host."""
+
+    def __init__(self, length):
+        self.shape = (int(length), 4)
+
+    def __getitem__(self, sl):
+        r0, r1, step = sl.indices(self.shape[0])
+        t = np.arange(r0, r1, dtype=np.int64)
+        d = t // 24
+        return np.stack([t % 24, (d + 4) % 7, d % 30 + 1, (d // 30) % 12 + 1], axis=1).astype(np.float64)
