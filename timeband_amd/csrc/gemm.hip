@@ -349,10 +349,63 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
                          ws_bytes, stream, accumulate);
 }
 
-// bias2: optional second bias vector; the epilogue adds (bias + bias2), the two summed first
+static int gemm_launch_one(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                           long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
+                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
+
+// bias2: optional second bias vector; the epilogue adds (bias + bias2), the two summed first.
+// The kernel addresses A and B through 32-bit buffer offsets (2 GiB each).  Larger operands -- the long-context
+// shapes: 2048 rows x 1024 steps x 4H floats of gates are 17 GB -- are cut here: along M when A is [M][K] (the
+// projections and dx: independent row blocks of C), along K when A is [K][M] (the weight gradients: K = rows x
+// steps; later pieces accumulate into C), at multiples of the B-shift period so that no shifted row crosses a cut.
 int tb_gemm_launch2(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                     long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
                     int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
+  if (M <= 0 || N <= 0) return TB_OK;
+  if (K <= 0) return tb_set_error(TB_ERR_ARG, "gemm: K must be positive");
+  constexpr long long kLimit = 0x7FFFFFF0ll / 4;   // floats
+  const long long exA = transA ? (long long)(K - 1) * lda + M : (long long)(M - 1) * lda + K;
+  const long long exB = transB ? (long long)(K - 1) * ldb + N : (long long)(N - 1) * ldb + K;
+  if (exA < kLimit && exB < kLimit)
+    return gemm_launch_one(A, lda, transA, B, ldb, transB, C, ldc, bias, bias2, M, N, K, act, b_shift, b_period, ws,
+                           ws_bytes, stream, accumulate);
+  if (!transA) {
+    if (exB >= kLimit) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: B operand larger than 2 GiB (%lld bytes)", exB * 4);
+    if (b_shift) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: shifted B with a row-major A larger than 2 GiB");
+    long long rows = (kLimit - K) / lda;
+    if (rows >= 1024) rows = rows / 1024 * 1024;
+    if (rows < 1) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: one row of A exceeds 2 GiB");
+    for (long long m0 = 0; m0 < M; m0 += rows) {
+      const int mc = (int)((M - m0) < rows ? (M - m0) : rows);
+      const int rc = gemm_launch_one(A + m0 * lda, lda, 0, B, ldb, transB, C + m0 * ldc, ldc, bias, bias2, mc, N, K, act,
+                                     0, b_period, ws, ws_bytes, stream, accumulate);
+      if (rc) return rc;
+    }
+    return TB_OK;
+  }
+  // A is [K][M]: cut K; B must be cut the same way ([K][N])
+  if (!transB) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: A^T larger than 2 GiB needs B as [K][N]");
+  if (act || bias || bias2) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: K-cut product with an epilogue");
+  const long period = b_period > 0 ? b_period : 1;
+  long long kc = (kLimit - M) / lda;
+  const long long kcB = (kLimit - N) / ldb;
+  if (kcB < kc) kc = kcB;
+  kc = kc / period * period;
+  if (kc < 1) return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: one shift period of A^T exceeds 2 GiB");
+  if (!ws || ws_bytes < (size_t)M * N * sizeof(float))
+    return tb_set_error(TB_ERR_WORKSPACE, "gemm: a K-cut product needs a workspace of M x N floats");
+  for (long long k0 = 0; k0 < K; k0 += kc) {
+    const int kk = (int)((K - k0) < kc ? (K - k0) : kc);
+    const int rc = gemm_launch_one(A + k0 * lda, lda, 1, B + k0 * ldb, ldb, 1, C, ldc, nullptr, nullptr, M, N, kk, 0,
+                                   b_shift, b_period, ws, ws_bytes, stream, (k0 > 0 || accumulate) ? 1 : 0);
+    if (rc) return rc;
+  }
+  return TB_OK;
+}
+
+static int gemm_launch_one(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
+                           long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
+                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
   if (M <= 0 || N <= 0) return TB_OK;
   if (accumulate && (!ws || ws_bytes < (size_t)M * N * sizeof(float)))
     return tb_set_error(TB_ERR_WORKSPACE, "gemm: accumulate needs a workspace of M x N floats");
