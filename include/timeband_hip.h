@@ -58,6 +58,13 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
                 int* err, void* stream);
 
+/* The weight-gradient products of tb_lstm_bwd on their own (autograd of source/utils/lstm_layer.py:44-46,83):
+ * dw_ih (4H,in) = dG^T.x, dw_hh (4H,H) = dG^T.h_prev with `dgates` = the gates buffer AFTER tb_lstm_bwd.  Call
+ * tb_lstm_bwd with dw_ih = dw_hh = NULL and this on another stream behind it: only dx is on the backward chain. */
+size_t tb_lstm_wgrad_workspace_bytes(int in_dim, int H);
+int tb_lstm_wgrad(const float* x, const float* y, const float* dgates, float* dw_ih, float* dw_hh, int B, int T,
+                  int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* tb_lstm_fwd for callers that CANNOT ALLOCATE (tight serving loops such as the cleaning pass, harnesses
  * that forbid hipMalloc, code that runs while a capture is open elsewhere).  No counterpart in the reference.  Same arguments
  * and results as tb_lstm_fwd minus the workspace: the exchange area (handshake tags + h ring) is a static

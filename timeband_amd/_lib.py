@@ -31,6 +31,8 @@ SIGNATURES = {
     "tb_lstm_supported": (I, [I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_wgrad_workspace_bytes": (Z, [I, I]),
+    "tb_lstm_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "tb_lstm_static_init": (I, []),
     "tb_lstm_static_scratch_bytes": (Z, []),
     "tb_lstm_fwd_static": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),

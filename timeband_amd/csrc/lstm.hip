@@ -1179,7 +1179,7 @@ constexpr unsigned long long kTimeoutTicks = 200000000ull;   // 2 s of the 100 M
 
 // the kernels address one cluster's rows through 32-bit buffer descriptors
 bool tile_fits_descriptor(const Plan& p, int T, int H) {
-  return (long long)p.rows_per_cluster * T * 4 * H * 4 < 0x7FFFFFFFll;
+  return (long long)p.rows_per_cluster * T * 4 * H * 4 < 0x7FFFFF00ll;
 }
 
 // workspace carve: [hello | exchange (fwd: h ring, bwd: dh slabs) | dbpart | gemm split-k slabs]
@@ -1387,6 +1387,36 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   if (dw_hh) {  // dW_hh = dG^T . h_prev,  h_prev[b,t] = y[b,t-1], 0 at t = 0
     rc = tb_gemm_launch(gates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, c.gemm_ws,
                         c.gemm_ws_bytes, s, accumulate);
+    if (rc) return rc;
+  }
+  return TB_OK;
+}
+
+size_t tb_lstm_wgrad_workspace_bytes(int in_dim, int H) {
+  (void)in_dim; (void)H;
+  return tb_align_up(tb_gemm_ws_bytes(), 256);
+}
+
+// The two weight-gradient products of tb_lstm_bwd on their own: dW_ih = dG^T.x, dW_hh = dG^T.h_prev.  A caller
+// that passes dw_ih = dw_hh = NULL to tb_lstm_bwd can run them here on ANOTHER stream (after an event behind
+// tb_lstm_bwd): nothing of the backward chain depends on them -- only dx feeds the layer below -- and beside
+// the latency-bound BPTT kernel of that layer they use HBM bandwidth that would otherwise idle.
+int tb_lstm_wgrad(const float* x, const float* y, const float* dgates, float* dw_ih, float* dw_hh, int B, int T,
+                  int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B <= 0 || T <= 0) return TB_OK;
+  if (!x || !y || !dgates || !ws) return tb_set_error(TB_ERR_ARG, "lstm_wgrad: null pointer");
+  if (ws_bytes < tb_lstm_wgrad_workspace_bytes(in_dim, H)) return tb_set_error(TB_ERR_WORKSPACE, "lstm_wgrad: workspace too small");
+  const int M = B * T;
+  int rc;
+  if (dw_ih) {
+    rc = tb_gemm_launch(dgates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, nullptr, 4 * H, in_dim, M, 0, 0, 1,
+                        static_cast<float*>(ws), ws_bytes, s, accumulate);
+    if (rc) return rc;
+  }
+  if (dw_hh) {
+    rc = tb_gemm_launch(dgates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, static_cast<float*>(ws),
+                        ws_bytes, s, accumulate);
     if (rc) return rc;
   }
   return TB_OK;

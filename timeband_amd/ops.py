@@ -37,6 +37,7 @@ def _f32c(t):
 class Runtime:
     """Per-device scratch: one growable workspace, the sticky error words, lazily initialised."""
     _by_device = {}
+    wgrad_overlap = False      # set by the trainer: LSTM weight-gradient GEMMs on the side stream below
 
     def __init__(self, device):
         self.device = device
@@ -61,6 +62,22 @@ class Runtime:
         if ws is None or ws.numel() < nbytes:
             ws = self._ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return ws
+
+    # Weight-gradient stream.  The dW_ih / dW_hh products of an LSTM layer's backward read the 268-537 MB
+    # dgates matrix but feed nothing in the backward chain (only dx does): with `wgrad_overlap` on they are
+    # queued on ONE side stream per device -- one, so that the passes that add into the same gradient slots
+    # keep their order -- beside the latency-bound BPTT kernels of the layers below.  Whoever reads or
+    # overwrites parameter gradients afterwards (optimizer step, all-reduce, zero_grad) calls join_wgrad().
+    def wgrad_stream(self):
+        if getattr(self, "_wg", None) is None:
+            self._wg = torch.cuda.Stream(self.device)
+            self._wg_dirty = False
+        return self._wg
+
+    def join_wgrad(self):
+        """The current stream waits for every weight-gradient product queued so far."""
+        if getattr(self, "_wg", None) is not None and self._wg_dirty:
+            torch.cuda.current_stream(self.device).wait_stream(self._wg)
 
     def check(self):
         """Host sync: raise if a persistent kernel reported an inter-workgroup wait timeout."""
@@ -161,9 +178,23 @@ class _LSTMLayerFn(torch.autograd.Function):
             db_hh = torch.empty(4 * H, dtype=torch.float32, device=dev) if need[4] else None
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 1)
         ws = rt.workspace(nws)
+        side = slots is not None and Runtime.wgrad_overlap and (dw_ih is not None or dw_hh is not None)
         _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
-                  _ptr(dx), _ptr(dw_ih), _ptr(dw_hh), _ptr(db_ih), _ptr(db_hh), B, T, In, H,
-                  1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+                  _ptr(dx), _ptr(None if side else dw_ih), _ptr(None if side else dw_hh), _ptr(db_ih), _ptr(db_hh),
+                  B, T, In, H, 1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+        if side:
+            cur = torch.cuda.current_stream(dev)
+            wg = rt.wgrad_stream()
+            wg.wait_stream(cur)
+            with torch.cuda.stream(wg):
+                ws2 = rt.workspace(lib.tb_lstm_wgrad_workspace_bytes(In, H))
+                _lib.call("tb_lstm_wgrad", _ptr(x), _ptr(y), _ptr(gates), _ptr(dw_ih), _ptr(dw_hh), B, T, In, H, 1,
+                          _ptr(ws2), ws2.numel(), _stream())
+                for t in (x, y, gates):
+                    t.record_stream(wg)
+                rt._wg_dirty = True
+                grads_enqueued(slots, ctx.params)      # an armed reducer records its event on THIS stream
+            return dx, None, None, None, None, None
         if slots is not None:
             grads_enqueued(slots, ctx.params)
             return dx, None, None, None, None, None

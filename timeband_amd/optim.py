@@ -97,8 +97,12 @@ class _FlatOptimizer:
         self.lr = lr
         self._reducer = None
 
+    def _join(self):
+        ops.Runtime.get(self.flat.grad.device).join_wgrad()     # weight-gradient products on the side stream
+
     def zero_grad(self, set_to_none: bool = False):
         self.flat.check()
+        self._join()
         self.flat.grad.zero_()
 
     # Data parallel: sum all-reduce of the gradient buffer (the loss kernels already divide by GLOBAL counts).
@@ -111,6 +115,7 @@ class _FlatOptimizer:
             self._reducer.arm()
 
     def all_reduce_grads(self):
+        self._join()
         if not dp.active():
             self._reducer = None
             return
@@ -132,6 +137,7 @@ class FusedAdam(_FlatOptimizer):
         self.t = 0
 
     def step(self):
+        self._join()
         self.t += 1
         ops.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1],
                       self.eps)
@@ -146,6 +152,7 @@ class FusedRMSprop(_FlatOptimizer):
         self.sq = None          # allocated only if the optimizer outlives one step
 
     def step(self):
+        self._join()
         if self.sq is None:
             self.sq = torch.empty_like(self.flat.data)
             ops.rmsprop_step(self.flat.data, self.flat.grad, self.sq, self.lr, self.alpha, self.eps, fresh=True)

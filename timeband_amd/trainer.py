@@ -53,6 +53,10 @@ class TIMEBANDTrainer:
         # in the upstream gradient -- one generator forward and ONE backward with the summed gradient give
         # the same update up to fp32 rounding of that sum.
         self.share_gpass = os.environ.get("TB_SHARE_GPASS", "0") == "1"
+        # TB_WGRAD_OVERLAP=1 (default off: measured zero-sum, 9.10 vs 9.06 ms -- the GEMMs and the BPTT kernels of the
+        # layers below slow each other by what the overlap gains): the LSTM weight-gradient GEMMs of every backward pass go to a side
+        # stream (ops.Runtime.wgrad_stream); the optimizers join it before they read the gradients
+        self.wgrad_overlap = os.environ.get("TB_WGRAD_OVERLAP", "0") == "1"
         self._side = None
 
     def set_config(self, config: dict = None) -> None:
@@ -140,6 +144,7 @@ class TIMEBANDTrainer:
         batch of `n_global` windows (default: equal slices on every rank).  Returns the G-phase fake_y."""
         netD, netG = self.models.netD, self.models.netG
         overlap = self.overlap and training and true_x.is_cuda
+        ops.Runtime.wgrad_overlap = bool(self.wgrad_overlap and training and true_x.is_cuda)
         # which parts overlap (TB_OVERLAP bit mask, default 5): 1 = D-phase generator forward under the
         # critic step, 2 = G-phase generator forward under the D-phase backward, 4 = graph cut at fake_y
         # (the generator's share of errD.backward() runs on the stream of its forward -- the side stream
@@ -258,6 +263,7 @@ class TIMEBANDTrainer:
         if training:
             self.optimG.all_reduce_grads()
             self.optimG.step()
+        ops.Runtime.wgrad_overlap = False
         return fake_y.detach()
 
     def train_step(self, epoch: int, dataset, training: bool = True):
