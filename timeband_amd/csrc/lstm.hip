@@ -119,6 +119,7 @@ struct FwdArgs {
   int* err;            // [4] sticky error words
   int B, T;
   int b_begin;         // first batch row of this launch
+  int rows;            // batch rows per cluster: 16 * MT, or fewer valid rows of a 16-row tile (see make_plan)
   int nclusters;
   int train;
   unsigned long long timeout_ticks;
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
   const int uw = j * US + ug * 16 + col;               // W_hh row (per gate) this lane feeds to the MFMA
   const int u0 = j * US + ug * 16 + q * 4 + kp * UPW;  // first of the UPW hidden units this lane finishes
-  const int b0 = a.b_begin + cl * 16 * MT;
+  const int b0 = a.b_begin + cl * a.rows;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
   if (tid == 0) *s_dead = 0;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   }
   // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
   int vrows = a.B - b0;
-  if (vrows > 16 * MT) vrows = 16 * MT;
+  if (vrows > a.rows) vrows = a.rows;
   const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (long)b0 * rowP), 0, (int)(vrows * rowP * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
@@ -714,6 +715,7 @@ struct BwdArgs {
   int* err;
   int B, T;
   int b_begin;
+  int rows;            // batch rows per cluster (<= 16 * MT)
   int cl_begin;        // index of this launch's first cluster in dbpart
   int nclusters;
   unsigned long long timeout_ticks;
@@ -748,14 +750,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int col = lane & 15, q = lane >> 4;
   int cl, j;
   cluster_decode(NCL, cl, j);
-  const int b0 = a.b_begin + cl * 16 * MT;
+  const int b0 = a.b_begin + cl * a.rows;
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
   constexpr int XSLAB = NCL * NCL * MT * 16 * US;  // floats per slab
   float* Xc = a.X + (size_t)cl * 3 * XSLAB;
   if (tid == 0) *s_dead = 0;
   int vrows = a.B - b0;
-  if (vrows > 16 * MT) vrows = 16 * MT;
+  if (vrows > a.rows) vrows = a.rows;
   const __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + (long)b0 * rowG), 0, (int)(vrows * rowG * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cst + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
@@ -1116,7 +1118,18 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   auto fits = [=](int mt) { return NCL == 1 || (fwd ? lds_f(mt) : lds_b(mt)) <= kLdsHalf; };
   while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters && fits(2 * MT)) MT *= 2;
   p.MT = MT;
-  p.rows_per_cluster = 16 * MT;
+  // Fewer VALID rows per 16-row MFMA tile when the batch has far fewer tiles than the chip has clusters (hidden 64
+  // at batch 512: 32 workgroups on 256 CUs).  A step's cost there is the workgroup's own memory pipe -- 24 KB of
+  // stash per step and CU: 1.39 us per step in training against 0.90 without the stash -- so the same rows are
+  // spread over 2 or 4 times as many workgroups, each computing a 16-row tile of which only 8 or 4 rows exist
+  // (the descriptors drop the rest).  Results per row do not depend on the tile they sit in.
+  int rows = 16 * MT;
+  if (MT == 1 && p.NCL == 1 && fwd) {   // (measured: no gain for BPTT or for the clustered variants)
+    const char* e = getenv("TB_TILE_ROWS");     // experiment knob: lower bound 16 / 8 / 4 (16 = always whole tiles)
+    const int floor_rows = (e && (atoi(e) == 16 || atoi(e) == 8)) ? atoi(e) : 4;
+    while (rows > floor_rows && (B + rows / 2 - 1) / (rows / 2) <= max_clusters) rows /= 2;
+  }
+  p.rows_per_cluster = rows;
   p.clusters_per_launch = max_clusters;
   p.lds_fwd = lds_f(MT);
   p.lds_bwd = lds_b(MT);
@@ -1208,7 +1221,7 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   const size_t hello_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * p.NCL * sizeof(unsigned long long), 256) : 0;
   // rings of 3 slots per cluster: forward rows x H floats (h_t all-gather), backward NCL x rows x H
   // (one partial of dh per producer, reduce-scatter)
-  const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * p.rows_per_cluster * H * sizeof(float), 256) : 0;
+  const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * (16 * p.MT) * H * sizeof(float), 256) : 0;
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   (void)in_dim;
   const size_t gemm_bytes = bwd ? tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
@@ -1260,6 +1273,7 @@ static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, c
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
+    a.rows = p.rows_per_cluster;
     a.nclusters = ncl;
     a.train = train;
     a.timeout_ticks = kTimeoutTicks;
@@ -1359,6 +1373,7 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     a.err = err;
     a.B = B; a.T = T;
     a.b_begin = c0 * p.rows_per_cluster;
+    a.rows = p.rows_per_cluster;
     a.cl_begin = c0;
     a.epoch = next_epoch();
     a.nclusters = ncl;

@@ -54,26 +54,27 @@ def run(jobs, reps=6):
     return [t / reps for t in tot]
 
 
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-pairs = [
-    (("fwd", 512, 32, 256), ("fwd", 512, 32, 256)),
-    (("fwd", 512, 32, 256), ("fwd", 512, 64, 128)),
-    (("bwd", 512, 32, 256), ("fwd", 512, 32, 256)),
-    (("bwd", 1024, 32, 256), ("fwd", 512, 32, 256)),
-    (("bwd", 1024, 32, 256), ("fwd", 512, 64, 128)),
-    (("bwd", 512, 32, 256), ("bwd", 512, 128, 256)),
-    (("fwd", 1024, 32, 256), ("fwd", 512, 36, 64)),
-]
-for pa, pb in pairs:
-    la, lb = Layer(pa[1], pa[2], pa[3], 1), Layer(pb[1], pb[2], pb[3], 2)
+if __name__ == "__main__":
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    pairs = [
+        (("fwd", 512, 32, 256), ("fwd", 512, 32, 256)),
+        (("fwd", 512, 32, 256), ("fwd", 512, 64, 128)),
+        (("bwd", 512, 32, 256), ("fwd", 512, 32, 256)),
+        (("bwd", 1024, 32, 256), ("fwd", 512, 32, 256)),
+        (("bwd", 1024, 32, 256), ("fwd", 512, 64, 128)),
+        (("bwd", 512, 32, 256), ("bwd", 512, 128, 256)),
+        (("fwd", 1024, 32, 256), ("fwd", 512, 36, 64)),
+    ]
+    for pa, pb in pairs:
+        la, lb = Layer(pa[1], pa[2], pa[3], 1), Layer(pb[1], pb[2], pb[3], 2)
 
-    def job(kind, layer, s):
-        return (s, None, layer.fwd) if kind == "fwd" else (s, layer.fwd, layer.bwd)
+        def job(kind, layer, s):
+            return (s, None, layer.fwd) if kind == "fwd" else (s, layer.fwd, layer.bwd)
 
-    ja, jb = job(pa[0], la, s1), job(pb[0], lb, s2)
-    (ta,) = run([ja])
-    (tb,) = run([jb])
-    ca, cb = run([ja, jb])
-    print(f"{pa[0]} {la.name:10s} alone {ta:.3f}  | {pb[0]} {lb.name:10s} alone {tb:.3f}  | together "
-          f"{ca:.3f} / {cb:.3f}   (serial {ta + tb:.3f}, max {max(ca, cb):.3f})", flush=True)
-ops.check_errors()
+        ja, jb = job(pa[0], la, s1), job(pb[0], lb, s2)
+        (ta,) = run([ja])
+        (tb,) = run([jb])
+        ca, cb = run([ja, jb])
+        print(f"{pa[0]} {la.name:10s} alone {ta:.3f}  | {pb[0]} {lb.name:10s} alone {tb:.3f}  | together "
+              f"{ca:.3f} / {cb:.3f}   (serial {ta + tb:.3f}, max {max(ca, cb):.3f})", flush=True)
+    ops.check_errors()
