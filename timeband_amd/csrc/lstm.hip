@@ -900,6 +900,23 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       __syncthreads();
       STAMP(2);
       if (NCL > 1 && *s_dead) break;   // a re-poll timed out (set before the barrier: uniform)
+      // (B0) Re-arm what the previous step consumed: this member's whole region of that step's slab -- its own
+      // never-written slot included -- as linear 16-byte pieces (whole lines; per-item 8-byte stores to 7 places
+      // took 7 store instructions of 16 partial lines each).  Every thread's loads of that region completed
+      // before the barrier above (their sums feed the gate math that precedes it), so any thread may re-arm any
+      // word.  The slab of step t+1 is written again at step t-2; its writers get there only after consuming this
+      // member's partial of step t-1, which is stored after the NEXT step's copy of the reduce-scatter wait --
+      // and that wait covers these stores.  So the re-arm always lands before the next write.
+      if (NCL > 1 && t < T - 1) {
+        const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+        constexpr int PER = NCL * MT * 16 * US / 4;   // 16-byte pieces of this member's region
+        const long rb = (long)((t + 1) % 3) * XSLAB + (long)j * NCL * MT * 16 * US;
+#pragma unroll
+        for (int i = 0; i < (PER + 255) / 256; ++i) {
+          const int pc = tid + 256 * i;
+          if (PER % 256 == 0 || pc < PER) stx4(same_l2, rX, rb + (long)pc * 4, arm);
+        }
+      }
       // (B) partial dh_{t-1}^T = W_hh[rows of this member]^T . dgates_t^T
       if (mactive) {
 #pragma unroll
@@ -1016,20 +1033,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int r = 0; r < UI; ++r) s[r] += other ? v[m][r] : 0.f;
           }
-          {
-            // Re-arm what was consumed.  The slab of step t is written again at step t-3; its writer
-            // gets there only after consuming this member's partial of step t-2, which is stored
-            // after the barrier that follows the NEXT step's copy of this wait -- and that wait
-            // covers these stores.  So the re-arm always lands before the next write.
-            // (the builtin, not inline asm: the compiler then KNOWS every earlier load has landed -- the
-            // prefetched stash of the next step included -- and does not start the next step's gate math
-            // with a vmcnt(0) behind these re-arm stores)
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-            const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
-#pragma unroll
-            for (int m = 0; m < NCL; ++m)
-              if (m != j) stxn<UI>(same_l2, rX, base + (long)m * MT * 16 * US, arm);
-          }
+          // (what was consumed is re-armed at the top of the next step, as whole lines: see (B0) there)
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the compiler then KNOWS every earlier load has landed --
+                                                // the prefetched stash of the next step included -- and does not
+                                                // start the next step's gate math with a wait of its own
         }
         dhrec[n] = s;
       }
