@@ -123,7 +123,7 @@ struct Tile {
 // FAST: both operands and the output are 16-byte addressable (pointers and leading dimensions multiples
 // of 4 floats, N a multiple of 4): one b128 load per chunk, one b128 store per epilogue piece, no
 // per-lane branches anywhere in the loop.  Otherwise dword loads / scalar tail stores.
-template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN, bool FAST>
+template <int LAY_A, int LAY_B, int BM, int BN, int WGM, int WGN, bool FAST, int PF = 1>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   using TA = Tile<LAY_A, BM>;
   using TB = Tile<LAY_B, BN>;
@@ -155,10 +155,129 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
     kbeg = z * a.kchunk;
     kend = min(a.K, kbeg + a.kchunk);
   };
-  int m0, n0, z, kbeg, kend;
-  decode(w, m0, n0, z, kbeg, kend);
   const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.bytesA, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.bytesB, 0x00020000);
+  if constexpr (PF == 2) {
+    // Operand tiles fetched TWO k-tiles ahead.  With one tile in flight per workgroup (two per CU) the loop ran at
+    // the latency of a first-touch HBM read: 2.3 us per k-tile against 0.36 us of MFMA issue -- neither the
+    // products, nor the bf16 split, nor the stores bounded it (a build without MFMAs took 0.188 ms where the full
+    // one takes 0.208).  The stream of (item, k-tile) pairs of this block is flattened: `ld` runs two tiles
+    // ahead of `cp` across item boundaries, the two register sets are refilled right after their tile has gone
+    // to LDS, and the A fragments are read per row block to make room for the second set.
+    struct Pos { int w, m0, n0, z, k, kend; bool valid; };
+    auto first = [&](Pos& p, int w_) {
+      p.w = w_;
+      p.valid = w_ < total;
+      p.m0 = p.n0 = p.z = p.k = p.kend = 0;
+      if (p.valid) decode(w_, p.m0, p.n0, p.z, p.k, p.kend);
+    };
+    auto advance = [&](Pos& p) {
+      p.k += BK;
+      if (p.k >= p.kend) first(p, p.w + (int)gridDim.x);
+    };
+    Pos ld, cp;
+    first(ld, w);
+    cp = ld;
+    f32x4 ra0[TA::NCH], rb0[TB::NCH], ra1[TA::NCH], rb1[TB::NCH];
+    auto issue = [&](f32x4 (&ra)[TA::NCH], f32x4 (&rb)[TB::NCH]) {
+      if (ld.valid) {
+        TA::template load<FAST>(rA, a.lda, ld.m0, a.M, ld.k, ld.kend, 0, 1, ra);
+        TB::template load<FAST>(rB, a.ldb, ld.n0, a.N, ld.k, ld.kend, a.b_shift, a.b_period, rb);
+        advance(ld);
+      }
+    };
+    issue(ra0, rb0);
+    issue(ra1, rb1);
+    f32x4 acc[TM][TN];
+    f32x4 bv;
+    auto new_item = [&]() {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (a.bias && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb2_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (a.bias2 && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const int nb = cp.n0 + wn * CW + (lane % (CW / 4)) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        bv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, (nb + r) * 4, 0, 0)) +
+                __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2_, (nb + r) * 4, 0, 0));
+    };
+    new_item();
+    auto half = [&](f32x4 (&ra)[TA::NCH], f32x4 (&rb)[TB::NCH]) -> bool {
+      TA::store(Ah, Al, ra);
+      TB::store(Bh, Bl, rb);
+      __syncthreads();
+      issue(ra, rb);          // the tile two ahead, into the registers that have just been emptied
+      bf16x8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
+        bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bf16x8 ah = TA::frag(Ah, (wm * TM + i) * 16, col, q);
+        const bf16x8 al = TA::frag(Al, (wm * TM + i) * 16, col, q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();   // all fragment reads done before the next tile overwrites the images
+      if (cp.k + BK >= cp.kend) {
+        // epilogue of the finished item (as in the one-tile-ahead form below)
+        float* out = a.splits > 1 ? a.slab + (size_t)cp.z * a.M * a.N : a.C;
+        const long ldo = a.splits > 1 ? a.N : a.ldc;
+        float* pw = patch[wave];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(pw + col * PLD + j * 16 + q * 4) = acc[i][j];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int k = 0; k < TN; ++k) {
+            const int idx = k * 64 + lane, row = idx / (CW / 4), c4 = idx % (CW / 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(pw + row * PLD + c4 * 4);
+            const int m = cp.m0 + (wm * TM + i) * 16 + row;
+            const int n = cp.n0 + wn * CW + c4 * 4;
+            if (m >= a.M || n >= a.N) continue;
+            if (a.splits == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] += bv[r];
+                if (a.act == 1) v[r] = tanhf(v[r]);
+                else if (a.act == 2) v[r] = tb_sigmoid(v[r]);
+              }
+            }
+            float* po = out + (long)m * ldo + n;
+            if (FAST) *reinterpret_cast<f32x4*>(po) = v;
+            else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (n + r < a.N) po[r] = v[r];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        advance(cp);
+        if (!cp.valid) return true;
+        new_item();
+        return false;
+      }
+      advance(cp);
+      return false;
+    };
+    while (true) {
+      if (half(ra0, rb0)) break;
+      if (half(ra1, rb1)) break;
+    }
+    return;
+  }
+  int m0, n0, z, kbeg, kend;
+  decode(w, m0, n0, z, kbeg, kend);
   f32x4 ra[TA::NCH], rb[TB::NCH];
   TA::template load<FAST>(rA, a.lda, m0, a.M, kbeg, kend, 0, 1, ra);
   TB::template load<FAST>(rB, a.ldb, n0, a.N, kbeg, kend, a.b_shift, a.b_period, rb);
@@ -314,10 +433,12 @@ __global__ void accumulate_kernel(const float* __restrict__ tmp, int M, int N, f
 
 template <int BM, int BN, int WGM, int WGN, bool FAST>
 void launch_lay(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
-  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 0, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
-  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 1, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
-  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 0, BM, BN, WGM, WGN, FAST>), grid, dim3(256), 0, stream, a);
+  // two k-tiles ahead where the registers allow it: the 128 x 128 tile (the 256-row tiles sit at 248-256 registers)
+  constexpr int PF = (BM == 128 && BN == 128 && FAST) ? 2 : 1;
+  if (transA == 0 && transB == 0) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 0, BM, BN, WGM, WGN, FAST, PF>), grid, dim3(256), 0, stream, a);
+  else if (transA == 0 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 1, BM, BN, WGM, WGN, FAST, PF>), grid, dim3(256), 0, stream, a);
+  else if (transA == 1 && transB == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 1, BM, BN, WGM, WGN, FAST, PF>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 0, BM, BN, WGM, WGN, FAST, PF>), grid, dim3(256), 0, stream, a);
 }
 
 template <int BM, int BN, int WGM, int WGN>
