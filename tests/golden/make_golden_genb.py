@@ -2,12 +2,14 @@
 """Golden vectors for the Gen-B API (tests/golden/genb.npz), made by RUNNING THE REFERENCE.
 
 What the reference can run here: source/losses.py (GANLoss, TimebandLoss) and source/metrics.py
-(TIMEBANDMetric) import cleanly; source/models.py and source/core.py do not (structlog is not
-installed, and core.py names classes it never imports), so the network comes from the reference's
-source/utils/lstm_layer.py -- the same architecture as models.py:10-117 -- and the Gen-B schedule of
-core.py:64-130 (persistent RMSprop critic with the LSGAN loss, D step, then a G step whose gradients
-start from zero) is driven from this script with the reference's own loss object and torch's
-optimizers.  Only inputs and outputs are written.
+(TIMEBANDMetric) import cleanly; source/core.py does not (it names classes it never imports), so the
+network comes from the reference's source/utils/lstm_layer.py -- the same architecture as
+models.py:10-117 -- and the Gen-B schedule of core.py:64-130 (persistent RMSprop critic with the LSGAN
+loss, D step, then a G step whose gradients start from zero) is driven from this script with the
+reference's own loss object and torch's optimizers.  source/models.py imports once `structlog` (not
+installed; only the logger's formatting uses it) is stood in for by an empty module object at import
+time: TimebandModel.predicts / adjust (models.py:173-215) are then run unbound on a bare instance --
+no Logger, no networks -- over three consecutive batches.  Only inputs and outputs are written.
 
     cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden_genb.py
 """
@@ -119,6 +121,39 @@ out.update({"metric.true": true, "metric.mask": mask, "metric.pred": pred,
             "metric.out": np.array([float(nmae), float(rmse), float(nme)])})
 sc = m.score(0)
 out["metric.score"] = np.array([sc["NME"], sc["NMAE"], sc["RMSE"]])
+
+# ---- TimebandModel.predicts / adjust (models.py:160-215): three consecutive batches, history carried
+import types  # noqa: E402
+from unittest import mock  # noqa: E402
+
+sys.modules.setdefault("structlog", mock.MagicMock(name="structlog"))   # logger.py:3,8-9 touch it at import
+from source.models import TimebandModel  # noqa: E402
+
+rng = np.random.default_rng(7)
+tm = TimebandModel.__new__(TimebandModel)      # the two methods read these four attributes only
+tm.forecast_len, tm.decode_dim = Tf, V
+tm.missing_gamma, tm.anomaly_gamma = 0.2, 0.3
+tm.pred_initiate()
+NB = 3
+series = rng.normal(size=(NB * B + Tf, V)) * 2 + 10
+miss = (rng.random((NB * B + Tf - 1, V)) < 0.15).astype(np.float64)
+out.update({"band.series": series, "band.miss": miss, "band.gammas": np.array([0.2, 0.3])})
+carry = series[0].copy()
+for k in range(NB):
+    pred = torch.tensor(series[1 + k * B:1 + k * B + B, None, :] + rng.normal(size=(B, Tf, V)) * 1.5, dtype=torch.float32)
+    pred[k, 1:3, 2] += 9.0                      # horizon outliers: wide std at a few rows
+    med, lo, up = tm.predicts(pred)
+    n = B + Tf - 1
+    output = np.concatenate([carry[None], series[1 + k * B:1 + k * B + n]])
+    output[3, 1] += 40.0                        # anomalies on both sides of the band
+    output[4, 3] -= 40.0
+    out[f"band.{k}.pred"] = pred.numpy().copy()
+    out[f"band.{k}.output"] = output.copy()
+    masks = miss[k * B:k * B + n]
+    target = tm.adjust(output, med, masks, lo, up)
+    out.update({f"band.{k}.median": med.copy(), f"band.{k}.lower": lo.copy(), f"band.{k}.upper": up.copy(),
+                f"band.{k}.target": np.array(target, copy=True)})
+    carry = target[B - 1].copy()                # the row before the next batch's first one
 
 np.savez_compressed(os.path.join(HERE, "genb.npz"), **out)
 print("wrote genb.npz with", len(out), "arrays")

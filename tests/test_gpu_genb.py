@@ -1,9 +1,9 @@
 """GPU: the Gen-B API (timeband_amd/models.py, losses.py, metrics.py, data.py, core.py) against what
 the reference's source/losses.py and source/metrics.py produced and the Gen-B schedule of
 source/core.py:64-130 driven with the reference's own loss object (tests/golden/genb.npz, made by
-tests/golden/make_golden_genb.py).  The band / adjust of source/models.py:173-215 cannot be run from
-the reference here (models.py needs structlog): it is checked against the oracle's restatement --
-parity unpinned for that one function beyond the Gen-A band goldens, which share its arithmetic."""
+tests/golden/make_golden_genb.py).  The band / adjust of source/models.py:173-215 is pinned by the
+reference's own TimebandModel.predicts / adjust run over three consecutive batches (genb.npz `band.*`),
+and checked against the oracle on further shapes."""
 import os
 
 import numpy as np
@@ -155,6 +155,23 @@ def test_predicts_and_adjust_vs_oracle(dev):
         want = O.adjust("genb", output.copy(), wmed, masks, wlo, wup, 0.2, 0.3)
         got = m.adjust(output, med, masks, lo, up)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+
+
+def test_predicts_and_adjust_vs_reference(z, dev):
+    """genb.npz band.*: what the reference's TimebandModel.predicts / adjust returned for three consecutive
+    batches -- NaN history first, then carried -- with horizon outliers, missing values and anomalies."""
+    from timeband_amd.models import TimebandModel
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    a, b = (float(v) for v in z["band.gammas"])
+    m = TimebandModel(E, V, H, To, Tf, device=dev, missing_gamma=a, anomaly_gamma=b)
+    for k in range(3):
+        med, lo, up = m.predicts(torch.tensor(z[f"band.{k}.pred"], device=dev))
+        np.testing.assert_allclose(med.cpu().numpy(), z[f"band.{k}.median"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lo.cpu().numpy(), z[f"band.{k}.lower"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(up.cpu().numpy(), z[f"band.{k}.upper"], rtol=1e-9, atol=1e-9)
+        n = B + Tf - 1
+        got = m.adjust(z[f"band.{k}.output"].copy(), med, z["band.miss"][k * B:k * B + n], lo, up)
+        np.testing.assert_allclose(got.cpu().numpy(), z[f"band.{k}.target"], rtol=1e-12, atol=1e-12)
 
 
 def test_core_end_to_end_on_csv(dev, tmp_path):

@@ -340,3 +340,20 @@ def test_genb_metric_scoring(golden_dir):
     t, p, m = z["metric.true"], z["metric.pred"], z["metric.mask"]
     nme, nmae, rmse = O.metrics(t, p[: t.shape[0]], m)
     np.testing.assert_allclose([nmae, rmse, nme], z["metric.out"], rtol=1e-9)
+
+
+def test_genb_band_and_adjust(golden_dir):
+    """models.py:173-215 run by the reference over three consecutive batches (history carried): the fixed
+    3*std band and the Gen-B ordering of the adjust scan (anomaly masks taken on the raw value)."""
+    z = load(golden_dir, "genb.npz")
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    a, b = z["band.gammas"]
+    band = O.Band(Tf, V, 3.0)
+    for k in range(3):
+        med, lo, up = band.predicts(z[f"band.{k}.pred"].astype(np.float64))
+        np.testing.assert_allclose(med, z[f"band.{k}.median"], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(lo, z[f"band.{k}.lower"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(up, z[f"band.{k}.upper"], rtol=1e-11, atol=1e-11)
+        n = B + Tf - 1
+        got = O.adjust("genb", z[f"band.{k}.output"].copy(), med, z["band.miss"][k * B:k * B + n], lo, up, a, b)
+        np.testing.assert_allclose(got, z[f"band.{k}.target"], rtol=1e-13, atol=1e-13)
