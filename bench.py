@@ -77,6 +77,29 @@ def pmc_traffic(family):
         return None, None
 
 
+def pmc_mfma():
+    """bf16 MFMA issue rate of the GEMM family from the latest committed counter summary (profiles/r*_mfma.json:
+    tools/gpu_profile.sh's SQ_INSTS_VALU_MFMA_MOPS_BF16 pass of this same command + tools/mfma_summary.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            z = json.load(f)
+        fam = z["families"]["gemm"]
+        big = max((k for k in z["kernels"] if "gemm" in k["kernel"]), key=lambda k: k["avg_us"] * k["launches"])
+        return {"bound": "mfma", "kernel": "gemm_bf16x3_kernel (all instantiations of one step)",
+                "achieved": round(fam["bf16_tflops"], 1), "peak": z["peak_bf16_tflops"], "unit": "TFLOP/s",
+                "frac": round(fam["mfma_frac"], 4), "fp32_equivalent_tflops": round(fam["bf16_tflops"] / 3, 1),
+                "largest_instantiation": {"kernel": big["kernel"], "bf16_tflops": round(big["bf16_tflops"], 1),
+                                          "mfma_busy": None if big["mfma_busy"] is None else round(big["mfma_busy"], 4)},
+                "source": os.path.basename(files[-1]) + " (rocprofv3 counter pass; every fp32-grade product is three "
+                          "bf16 MFMAs, so useful flops are a third of the issue rate)"}
+    except Exception:
+        return None
+
+
 def build(cfg, device, seed=31):
     from timeband_amd import synthetic
     from timeband_amd.dataset import TIMEBANDDataset
@@ -305,6 +328,18 @@ def main():
     barrier()
     ops.check_errors(device)
     prof = {name: read(k) for name, k in kids.items()}
+    # the dominant family alone on one stream (TB_OVERLAP=0): its launch time without a co-running kernel
+    mask = trainer.overlap_mask
+    trainer.overlap_mask, trainer.overlap = 0, False
+    step(args.warmup + args.steps + extra)
+    barrier()
+    lib.tb_prof_enable(kids[dom], 1)
+    for i in range(extra):
+        step(args.warmup + args.steps + extra + 1 + i)
+    barrier()
+    ops.check_errors(device)
+    solo = read(kids[dom])
+    trainer.overlap_mask, trainer.overlap = mask, mask != 0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -333,9 +368,15 @@ def main():
                          "traffic_source": traffic_src,
                          "launches": p["launches"],
                          "avg_launch_ms": round(p["total_ms"] / max(1, p["launches"]), 4),
-                         "algo_bytes_per_launch": round(p["algo_bytes"] / max(1, p["launches"]), 1)},
+                         "algo_bytes_per_launch": round(p["algo_bytes"] / max(1, p["launches"]), 1),
+                         "single_stream": {"avg_launch_ms": round(solo["total_ms"] / max(1, solo["launches"]), 4),
+                                           "achieved": round(solo["algo_bytes"] / max(solo["total_ms"], 1e-9) / 1e6, 2),
+                                           "frac": round(solo["algo_bytes"] / max(solo["total_ms"], 1e-9) / 1e6
+                                                         / HBM_PEAK_GBS, 5),
+                                           "note": f"{extra} untimed steps with TB_OVERLAP=0: no co-running kernel"}},
             "step_hbm_roofline": {"algo_bytes_per_window": abw,
                                   "frac": round(abw * value / world / (HBM_PEAK_GBS * 1e9), 5)},
+            "roofline_gemm": pmc_mfma() if args.config == "cfg2" else None,
             "kernel_ms_per_step": {k: round(v["total_ms"] / max(1, extra), 4) for k, v in prof.items()},
             "kernel_ms_per_step_source": f"{extra} extra untimed steps with every family's event timers on",
         }

@@ -144,3 +144,20 @@ def test_genb_data_front_end_on_cpu(tmp_path):
     sub_frame = pd.read_csv(d.target_path, parse_dates=["Date"]).iloc[-To - Tf:]
     predset = d.prepare_predset(sub_frame)
     assert len(predset) == Tf and predset.shape() == (Tf, To, V + 2)
+
+
+def test_whole_module_checkpoint_is_refused_with_guidance(tmp_path):
+    """The reference pickles whole modules (model.py:84-95); TIMEBANDModel.load never unpickles: such a file
+    ends in the documented RuntimeError, not in an UnpicklingError or the silent fallback to load("")."""
+    import torch
+    from timeband_amd.model import TIMEBANDModel
+    from timeband_amd.utils.logger import NullLogger
+    m = TIMEBANDModel({"logger": NullLogger(), "models_path": str(tmp_path), "load_opt": True})
+    m.netD, m.netG = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+    torch.save(m.netD, m.get_path("netD"))
+    torch.save(m.netG, m.get_path("netG"))
+    with pytest.raises(RuntimeError, match="not a state_dict checkpoint"):
+        m.load()
+    torch.save(m.netD.state_dict(), m.get_path("netD"))
+    torch.save(m.netG.state_dict(), m.get_path("netG"))
+    m.load()

@@ -124,6 +124,31 @@ def test_two_clustered_launches_side_by_side(dev):
     assert torch.equal(ya, ya2) and torch.equal(yb, yb2)
 
 
+def test_third_clustered_stream_is_held_back(dev):
+    """Three streams with full-chip clustered launches queued at once (what TB_OVERLAP=7 can do): only two such
+    launches fit a CU side by side, so ops.Runtime orders the third behind the oldest -- no wait timeout, and
+    the bits of launches that run alone."""
+    from timeband_amd import ops
+    rng = np.random.default_rng(13)
+    B, Tn, In, H = 512, 32, 36, 256
+    k = 1.0 / np.sqrt(H)
+    ps = [T(rng.uniform(-k, k, s), dev) for s in ((4 * H, In), (4 * H, H), (4 * H,), (4 * H,))]
+    xs = [T(rng.uniform(-1, 1, (B, Tn, In)), dev) for _ in range(3)]
+    with torch.no_grad():
+        alone = [ops.lstm_layer(x, *ps) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        for _ in range(4):
+            got = []
+            for s, x in zip(streams, xs):
+                with torch.cuda.stream(s):
+                    got.append(ops.lstm_layer(x, *ps))
+        torch.cuda.synchronize()
+    ops.check_errors()
+    for a, b in zip(alone, got):
+        assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_cfg4_long_context_two_layer_iteration(dev):
     """BASELINE.json configs[3] (window 1024, hidden 512, 2-layer) reduced to window 48 / batch 6: the D and

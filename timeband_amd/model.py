@@ -56,7 +56,13 @@ class TIMEBANDModel:
             if os.path.exists(pD) and os.path.exists(pG):
                 self.logger.info(f" - {postfix} Model Loading : {pD}, {pG}")
                 for path, net in ((pD, self.netD), (pG, self.netG)):
-                    sd = torch.load(path, map_location="cpu", weights_only=True)
+                    try:
+                        sd = torch.load(path, map_location="cpu", weights_only=True)
+                    except Exception as e:     # a whole pickled module (reference model.py:84-95): never unpickled here
+                        raise RuntimeError(
+                            f"{path} is not a state_dict checkpoint ({type(e).__name__}); the reference saves whole "
+                            "pickled modules -- convert once where the file is trusted: "
+                            "torch.save(torch.load(path, weights_only=False).state_dict(), path)") from e
                     if not isinstance(sd, dict):
                         raise RuntimeError(f"{path} is not a state_dict checkpoint")
                     net.load_state_dict(sd)      # in place: parameters keep aliasing their flat buffers

@@ -79,6 +79,39 @@ class Runtime:
         if getattr(self, "_wg", None) is not None and self._wg_dirty:
             torch.cuda.current_stream(self.device).wait_stream(self._wg)
 
+    # Co-residency guard.  A clustered recurrent launch (hidden > 64) makes progress only with ALL its workgroups
+    # resident, and every such variant is sized so that TWO launches fit side by side on a CU (256 of 512
+    # registers, 80 of 160 KiB LDS; csrc/lstm.hip make_plan).  A third one in flight -- three streams, e.g.
+    # TB_OVERLAP=7 -- can leave two launches each half resident, spinning until the 2 s timeout.  So before a
+    # clustered launch on stream S: of the OTHER streams with a clustered launch not yet known to be finished,
+    # all but the most recent one are waited for by S (oldest first).  With the default streams every such wait
+    # is on work S depends on anyway.
+    def clustered_begin(self):
+        cl = self.__dict__.setdefault("_clustered", {})
+        if not cl:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        live = []
+        for key, (seq, ev) in list(cl.items()):
+            if key == cur.cuda_stream:
+                continue
+            if ev.query():
+                del cl[key]
+            else:
+                live.append((seq, ev))
+        live.sort(key=lambda q: q[0])
+        for seq, ev in live[:-1]:
+            cur.wait_event(ev)
+
+    def clustered_end(self):
+        cl = self.__dict__.setdefault("_clustered", {})
+        cur = torch.cuda.current_stream(self.device)
+        self._cl_seq = getattr(self, "_cl_seq", 0) + 1
+        old = cl.get(cur.cuda_stream)
+        ev = old[1] if old is not None else torch.cuda.Event()
+        ev.record(cur)
+        cl[cur.cuda_stream] = (self._cl_seq, ev)
+
     def check(self):
         """Host sync: raise if a persistent kernel reported an inter-workgroup wait timeout."""
         e = self.err.tolist()
@@ -147,8 +180,12 @@ class _LSTMLayerFn(torch.autograd.Function):
         cst = torch.empty(B, T, H, dtype=torch.float32, device=x.device) if train else None
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 0)
         ws = rt.workspace(nws)
+        if H > 64:
+            rt.clustered_begin()
         _lib.call("tb_lstm_fwd", _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(y), _ptr(gates),
                   _ptr(cst), B, T, In, H, int(train), _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+        if H > 64:
+            rt.clustered_end()
         if train:
             ctx.save_for_backward(x, w_ih, w_hh, y, gates, cst)
             ctx.dims = (B, T, In, H)
@@ -179,9 +216,13 @@ class _LSTMLayerFn(torch.autograd.Function):
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 1)
         ws = rt.workspace(nws)
         side = slots is not None and Runtime.wgrad_overlap and (dw_ih is not None or dw_hh is not None)
+        if H > 64:
+            rt.clustered_begin()
         _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
                   _ptr(dx), _ptr(None if side else dw_ih), _ptr(None if side else dw_hh), _ptr(db_ih), _ptr(db_hh),
                   B, T, In, H, 1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+        if H > 64:
+            rt.clustered_end()
         if side:
             cur = torch.cuda.current_stream(dev)
             wg = rt.wgrad_stream()

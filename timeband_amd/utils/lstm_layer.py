@@ -3,9 +3,10 @@
 Drop-in for the reference's source/utils/lstm_layer.py (Gen-A signatures :18 and :68) and the Gen-B
 twins in source/models.py:23-31,91 (see `from_genb`).  The torch.nn.LSTM / nn.Linear sub-modules
 are kept ONLY as parameter containers: same construction order (so the same seed gives the same
-initial weights), same state_dict keys (`lstm0.weight_ih_l0`, `seq_layer.0.weight`, ...), so
-reference checkpoints load.  Their forward() is never called: all arithmetic goes through
-timeband_amd.ops (HIP kernels).
+initial weights), same state_dict keys (`lstm0.weight_ih_l0`, `seq_layer.0.weight`, ...), so a
+state_dict taken from a reference network loads.  (Only state_dict checkpoints are accepted: the
+reference's model.py:84-95 pickles whole modules, and TIMEBANDModel.load refuses to unpickle.)  Their
+forward() is never called: all arithmetic goes through timeband_amd.ops (HIP kernels).
 """
 import torch
 import torch.nn as nn

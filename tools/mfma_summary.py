@@ -8,7 +8,8 @@ flops are a third of it), SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES (both summ
 GRBM_GUI_ACTIVE (kernel cycles).  Reported per kernel name (one per template instantiation):
   bf16_tflops   = MOPS * 512 / duration            (dense bf16 MFMA issue, peak 2.5 PFLOP/s)
   mfma_frac     = bf16_tflops / 2500
-  mfma_busy     = MFMA_BUSY_CYCLES / (GUI_ACTIVE * 256 CUs * 4 SIMDs)   (rocprof's MfmaUtil)
+  mfma_busy     = MFMA_BUSY_CYCLES / (GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)   (rocprof's MfmaUtil; rocprofv3 reports
+                  GRBM_GUI_ACTIVE summed over the 8 XCDs, hence the / 8)
 Durations are the dispatch timestamps of the same pass (counter collection serialises kernels).
 usage: python tools/mfma_summary.py <counter_collection.csv> [out.json]"""
 import csv
@@ -48,7 +49,7 @@ for name, p in sorted(per.items(), key=lambda kv: -kv[1]["mops"]):
     tf = p["mops"] * 512 / p["seconds"] / 1e12 if p["seconds"] > 0 else 0.0
     rows.append(dict(kernel=name, launches=p["launches"], avg_us=p["seconds"] / p["launches"] * 1e6,
                      bf16_tflops=tf, mfma_frac=tf / PEAK_BF16_TFLOPS, fp32_equiv_tflops=tf / 3,
-                     mfma_busy=(p["mfma_busy"] / (p["gui"] * 256 * 4)) if p["gui"] > 0 else None,
+                     mfma_busy=(p["mfma_busy"] / (p["gui"] / 8 * 256 * 4)) if p["gui"] > 0 else None,
                      mfma_busy_of_sq_busy=(p["mfma_busy"] / p["sq_busy"]) if p["sq_busy"] > 0 else None))
 fam = {}
 for key in ("gemm", "lstm_fwd_kernel", "lstm_bwd_kernel"):
