@@ -75,6 +75,9 @@ MORE_LSTM_CASES = [
     (200, 20, 36, 512),     # hidden 512 forward with 2 tiles per cluster (k split over 4 waves, 32-member clusters)
     (1100, 5, 8, 256),      # 2 tiles per cluster AND a second launch
     (9, 130, 11, 16), (50, 64, 7, 32), (130, 48, 36, 64),   # single-workgroup layers, long sequences
+    # input projection fused into the recurrent kernel (in <= 64, a multiple of 4): one and two x k-steps, in < 32,
+    # several tiles per cluster, the padded 36 -> 64 case, hidden 16 / 32
+    (40, 9, 4, 16), (300, 21, 12, 32), (530, 17, 36, 64), (1100, 12, 64, 128), (96, 25, 28, 256), (70, 14, 60, 128),
 ]
 
 

@@ -109,7 +109,12 @@ constexpr int kBufFlags = 0x00020000;         // raw buffer descriptor word 3 (3
 constexpr int kSC1 = 16;                      // aux: sc1 = write-through store / L1-bypassing load
 
 struct FwdArgs {
-  float* P;            // [B][T][4H] in: pre-activations from the projection; out: activated gates
+  float* P;            // [B][T][4H] in: pre-activations from the projection (XK == 0); out: activated gates
+  const float* x;      // [B][T][in_dim]   } fused input projection (XK > 0): the kernel computes
+  const float* Wih;    // [4H][in_dim]     } x_t . W_ih^T + b_ih + b_hh itself and P is output only
+  const float* b_ih;   // [4H] or nullptr  }
+  const float* b_hh;   // [4H] or nullptr  }
+  int in_dim;
   const float* Whh;    // [4H][H]
   float* y;            // [B][T][H]
   float* cst;          // [B][T][H] cell stash (train) or nullptr
@@ -236,7 +241,12 @@ __device__ __forceinline__ bool armed(u32x4 v) {
   return v[0] == kSentinel || v[1] == kSentinel || v[2] == kSentinel || v[3] == kSentinel;
 }
 
-template <int H, int US, int KS, int MT>
+// XK > 0: the input projection is fused (in_dim <= XK, XK = 32 or 64): the member's W_ih rows sit in LDS as split
+// bf16 A-fragments, x_t tiles are fetched two steps ahead into a double-buffered LDS tile, and each step's MFMA block
+// gets XK / 32 more k-steps -- the projection GEMM, its [B][T][4H] output and the kernel's read of it are gone.  Whether
+// a layer is fused depends on (H, in_dim) only, never on the batch: every variant that can serve a layer does the same
+// arithmetic, so a window's result does not depend on the launch it is computed in.
+template <int H, int US, int KS, int MT, int XK>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NUG = US / 16;          // 16-unit groups per member
   constexpr int NCL = H / US;           // members per cluster
@@ -266,6 +276,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // written at the end of a step and flushed at the top of the next one, behind the barrier between them.
   constexpr bool STAGE = MT == 1 && NCL > 1 && KS == 2 && US == 32;
   constexpr int PROW = 4 * US + 8, SROW = 6 * US + 8;   // padded LDS rows: [4 gates][US], [4 gates, c, y][US]
+  constexpr bool FUSE = XK > 0;
+  constexpr int NXS = XK / 32;                          // x k-steps
+  constexpr int LDX = XK + 8;                           // LDS row stride of the W_ih / x tiles (bf16 elements)
+  constexpr int NXT = 16 * (XK / 4);                    // threads that move one 16-row x tile (16 bytes each)
+  constexpr int PBUF = (STAGE && !FUSE) ? 2 * 16 * PROW : 0, SBUF = STAGE ? 16 * SROW : 0;
+  static_assert(!FUSE || ((XK == 32 || XK == 64) && NXT <= 256 && (KS == 1 || KS == 2)), "bad fused-projection config");
   static_assert(NACT <= 4 && KPER % 32 == 0 && H % US == 0 && (KS == 1 || KS == 2 || KS == 4), "bad config");
   static_assert(NCL == 1 || (NACT == 4 && (16 * (US / 4)) % 64 == 0 && NLD <= 32 && NPP * NUG <= 64), "bad exchange config");
 
@@ -276,8 +292,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   float* red = smem + MT * 16 * LDH;                   // [NUG][KS dst][KS-1 src][64 lanes][4 gates][UPW]
   int* s_dead = reinterpret_cast<int*>(red + RED);
   int* s_word = s_dead + 1;
-  float* pbuf = red + RED + 4;                         // [2][16][PROW]   (STAGE)
-  float* sbuf = pbuf + 2 * 16 * PROW;                  // [16][SROW]      (STAGE)
+  float* pbuf = red + RED + 4;                         // [2][16][PROW]   (STAGE, not fused)
+  float* sbuf = pbuf + PBUF;                           // [16][SROW]      (STAGE)
+  unsigned short* wiH = reinterpret_cast<unsigned short*>(sbuf + SBUF);   // [4 gates][US][LDX] W_ih rows, bf16 hi  (FUSE)
+  unsigned short* wiL = wiH + 4 * US * LDX;                               //                               bf16 lo
+  unsigned short* xH = wiL + 4 * US * LDX;                                // [2][MT*16][LDX] x_t tiles (t & 1), bf16 hi
+  unsigned short* xL = xH + 2 * MT * 16 * LDX;
+  float* bsum = reinterpret_cast<float*>(xL + 2 * MT * 16 * LDX);        // [4 gates][US] b_ih + b_hh of the member's units
+  float* xkeep = bsum + 4 * US;                                          // [256 lanes][8]: see XLDS
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -311,6 +333,27 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(NCL > 1 ? a.ring + (size_t)cl * 3 * RS : a.y), 0, NCL > 1 ? 3 * RS * 4 : 0, kBufFlags);
+  // fused projection: this cluster's rows of x; every thread of the first NXT moves 16 bytes of a 16-row tile, the
+  // rest (and columns >= in_dim, steps >= T) ask for an out-of-range offset, which returns 0 without touching memory --
+  // so EVERY wave issues exactly one load per tile and step (the vmcnt guard before the publish counts on it)
+  const int in = FUSE ? a.in_dim : 0;
+  const long rowX = (long)T * in;
+  const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? a.x + (long)b0 * rowX : a.y), 0, FUSE ? (int)(vrows * rowX * 4) : 0, kBufFlags);
+  const int xr = tid / (FUSE ? XK / 4 : 1), xc = (tid % (FUSE ? XK / 4 : 1)) * 4;
+  const bool xmine = FUSE && tid < NXT && xc < in;
+  auto xload = [&](int tt, int mt) -> f32x4 {
+    const long off = (xmine && tt < T) ? ((long)(mt * 16 + xr) * rowX + (long)tt * in + xc) : 0x1FFFFFFFl;
+    return ldg4<0>(rX, off);
+  };
+  auto xstore = [&](int tt, int mt, f32x4 v) {
+    if (tid < NXT) {
+      u32x2 sh, sl;
+      tb_split4(v, sh, sl);
+      const int o = ((tt & 1) * MT * 16 + mt * 16 + xr) * LDX + xc;
+      *reinterpret_cast<u32x2*>(xH + o) = sh;
+      *reinterpret_cast<u32x2*>(xL + o) = sl;
+    }
+  };
 
   // W_hh fragments (A operand of v_mfma_f32_16x16x32_bf16), split into bf16 hi/lo, resident for the
   // whole sequence: A[m][k] = W_hh[g*H + uw][k], k-step s of this lane covers k = kp*KPER + s*32 + q*8 .. +7
@@ -328,12 +371,33 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       }
       tb_split8(v0, v1, whi[g][s], wlo[g][s]);
     }
+  if (FUSE) {
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wih, 0, 4 * H * in * 4, kBufFlags);
+    for (int i = tid; i < 4 * US * (XK / 4); i += 256) {
+      const int row = i / (XK / 4), c4 = (i % (XK / 4)) * 4, g = row / US, r = row % US;
+      const f32x4 v = ldg4<0>(rW, c4 < in ? (long)(g * H + j * US + r) * in + c4 : 0x1FFFFFFFl);
+      u32x2 sh, sl;
+      tb_split4(v, sh, sl);
+      *reinterpret_cast<u32x2*>(wiH + row * LDX + c4) = sh;
+      *reinterpret_cast<u32x2*>(wiL + row * LDX + c4) = sl;
+    }
+    for (int i = tid; i < 4 * US; i += 256) {
+      const int o = (i / US) * H + j * US + i % US;
+      bsum[i] = (a.b_ih ? a.b_ih[o] : 0.f) + (a.b_hh ? a.b_hh[o] : 0.f);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 v0 = xload(0, mt), v1 = xload(1, mt);
+      xstore(0, mt, v0);
+      xstore(1, mt, v1);
+    }
+  }
   float c[MT][UPW], pre[MT][4][UPW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const f32x4 v = (active && !STAGE) ? ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = (active && !STAGE && !FUSE) ? ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + g * H + u0) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < UPW; ++u) pre[mt][g][u] = v[u];
     }
@@ -341,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     for (int u = 0; u < UPW; ++u) c[mt][u] = 0.f;
   }
   bool same_l2 = false;
-  if (STAGE) {   // step 0's pre-activations into pbuf[0] (the handshake's barriers publish them)
+  if (STAGE && !FUSE) {   // step 0's pre-activations into pbuf[0] (the handshake's barriers publish them)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
@@ -359,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 
   // the first pre-activations are complete before the loop (see the note at the prefetch wait below):
   // otherwise the loop-carried `pre` counts as pending and the gate math starts with a vmcnt(0)
-  if (!STAGE) {
+  if (!STAGE && !FUSE) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -367,6 +431,87 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int u = 0; u < UPW; ++u) asm volatile("" : "+v"(pre[mt][g][u]));
   }
+  // (W_ih . x_tt^T) of tile mt into r (from zero): r[g] = gate g, or -- DEAL -- r[0], r[1] = gates kp, kp + 2
+  constexpr bool DEAL = FUSE && (NXS % KS != 0);
+  constexpr int NR = DEAL ? 2 : 4;
+  auto xraw = [&](int tt, int mt, f32x4 (&acc)[NR]) {
+#pragma unroll
+    for (int g = 0; g < NR; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (FUSE && active) {
+          // (W_ih . x_t^T): x k-step s goes to the k-part wave s % KS; with fewer x k-steps than k-part waves the
+          // gates are dealt out instead (the partial sums meet in the k-split swap below either way)
+          int opq = 0;   // opaque zero: keeps the loop-invariant W_ih reads in the loop (hoisted, they cost 32-64 registers)
+          asm volatile("" : "+v"(opq));
+          if constexpr (!DEAL) {
+#pragma unroll
+            for (int sx = 0; sx < NXS; ++sx) {
+              if (sx % KS != kp) continue;
+              const int xo = ((tt & 1) * MT * 16 + mt * 16 + col) * LDX + sx * 32 + q * 8;
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xH + xo));
+              const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xL + xo));
+              bf16x8 ah[4], al[4];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int wo = (g * US + ug * 16 + col) * LDX + sx * 32 + q * 8 + opq;
+                ah[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiH + wo));
+                al[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiL + wo));
+              }
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl, acc[g], 0, 0, 0);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[g], bh, acc[g], 0, 0, 0);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bh, acc[g], 0, 0, 0);
+            }
+          } else {
+            // one x k-step, two k-part waves: wave kp takes gates kp and kp + 2 (operands picked by address, the two
+            // results dealt into the accumulators by a wave-uniform select)
+            static_assert(NXS == 1 && KS == 2, "gate dealing is written for one k-step and two k-part waves");
+            const int xo = ((tt & 1) * MT * 16 + mt * 16 + col) * LDX + q * 8;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xH + xo));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xL + xo));
+            const int w0 = (kp * US + ug * 16 + col) * LDX + q * 8 + opq, w1 = w0 + 2 * US * LDX;
+            const bf16x8 ah0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiH + w0));
+            const bf16x8 al0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiL + w0));
+            const bf16x8 ah1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiH + w1));
+            const bf16x8 al1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiL + w1));
+            f32x4 t0 = acc[0], t1 = acc[1];
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, t1, 0, 0, 0);
+            t0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, t0, 0, 0, 0);
+            t1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, t1, 0, 0, 0);
+            acc[0] = t0;
+            acc[1] = t1;
+          }
+    }
+  };
+  auto xdeal = [&](const f32x4 (&r)[NR], f32x4 (&acc)[4]) {
+    if constexpr (DEAL) {
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      acc[0] = kp == 0 ? r[0] : zero;
+      acc[1] = kp == 0 ? zero : r[0];
+      acc[2] = kp == 0 ? r[1] : zero;
+      acc[3] = kp == 0 ? zero : r[1];
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = r[g];
+    }
+  };
+  // One tile per cluster: the x part of step t+1 is computed in the shadow of step t's hand-off (after the publish,
+  // before the poll) into the accumulators that the next MFMA block continues from -- the same operations in the same
+  // order as in the variants that do it at the top of the MFMA block, so the same bits.
+  constexpr bool XAHEAD = FUSE && MT == 1 && NCL > 1;
+  // Hidden 256 has no registers left to carry that across the pull (256 per lane is the co-residency limit): there the
+  // two accumulators wait in LDS.
+  constexpr bool XLDS = XAHEAD && H >= 256 && DEAL;
+  f32x4 accx[NR];
+  if (XAHEAD) xraw(0, 0, accx);
+  if (XLDS) {
+    *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0];
+    *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[NR > 1 ? 1 : 0];
+  }   // the handshake's barriers above made the W_ih rows and x_0 visible
   STAMP_DECL;
 #ifdef TB_STAMPS
   stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
@@ -418,14 +563,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // issued just before a poll holds the poll and the pull behind it (measured: +2000 cycles per step)
       float nxt[4][UPW];
       f32x4 pl[2];
-      if (STAGE && t + 1 < T) {
+      f32x4 xl = {0.f, 0.f, 0.f, 0.f};
+      if (FUSE) xl = xload(t + 2, mt);   // x_{t+2} of this tile, into the LDS half that x_t leaves in this phase
+      if (STAGE && !FUSE && t + 1 < T) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
           pl[i] = ldg4<0>(rP, (long)r * rowP + (long)(t + 1) * 4 * H + g * H + j * US + c4 * 4);
         }
       }
-      if (!STAGE && t + 1 < T && active) {
+      if (!STAGE && !FUSE && t + 1 < T && active) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = ldgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)(t + 1) * 4 * H + g * H + u0);
@@ -437,7 +584,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       f32x4 acc[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (t > 0 && active) {
+      if (FUSE) {
+        if (!XAHEAD) xraw(t, mt, accx);
+        if (XLDS) {
+          accx[0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8);
+          accx[NR > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8 + 4);
+        }
+        xdeal(accx, acc);
+      }
+      if ((FUSE || t > 0) && active) {
+        if (!FUSE || t > 0) {
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
           const int ho = (mt * 16 + col) * LDH + kp * KPER + s * 32 + q * 8;
@@ -450,6 +606,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][s], bh, acc[g], 0, 0, 0);
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc[g], 0, 0, 0);
+        }
         }
         if (KS > 1) {   // hand every other k-part wave of this unit group the partial sums of ITS units
 #pragma unroll
@@ -488,7 +645,16 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (active) {
         // (C) gate math, state update, h into LDS and the ring -- UPW consecutive units of one batch row per lane
         float z[4][UPW];
-        if (STAGE) {
+        if (FUSE) {
+          const float* pb = bsum + (u0 - j * US);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 w = UPW == 4 ? *reinterpret_cast<const f32x4*>(pb + g * US)
+                                     : (UPW == 2 ? (f32x4){pb[g * US], pb[g * US + 1], 0.f, 0.f} : (f32x4){pb[g * US], 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int u = 0; u < UPW; ++u) pre[mt][g][u] = w[u];
+          }
+        } else if (STAGE) {
           const float* pb = pbuf + (t & 1) * 16 * PROW + col * PROW + (u0 - j * US);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -501,7 +667,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int u = 0; u < UPW; ++u) z[g][u] = acc[g][kp * UPW + u] + pre[mt][g][u];
-        if (KS > 1 && t > 0) {
+        if (KS > 1 && (FUSE || t > 0)) {
 #pragma unroll
           for (int sr = 0; sr < KS; ++sr) {
             if (sr == kp) continue;
@@ -559,11 +725,29 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           STAMP(5);
           // The count is the MINIMUM any wave issues there: the wave that has this member among its producers
           // skips that producer's LPP early pull loads (a larger count would not force the re-arm to complete).
-          constexpr int AFTER_REARM = STAGE ? 2 : (MT == 1 ? 4 : 4 + NLD - LPP);
+          constexpr int NPF = FUSE ? 1 : (STAGE ? 2 : 4);   // prefetch loads every wave issues after the re-arm
+          constexpr int AFTER_REARM = MT == 1 ? NPF : NPF + NLD - LPP;
           static_assert(AFTER_REARM >= 0 && AFTER_REARM < 64, "vmcnt immediate");
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFTER_REARM) : "memory");
           STAMP(6);
           stxn<UPW>(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
+        }
+      }
+      if (STAGE) {
+        // y and the stash of this step into sbuf (flushed at the top of the next step; the flush of step t-1 read
+        // it before this step's first barrier).  Here rather than after the pull: it ends the life of st / hn
+        // before the pull buffers begin theirs.
+        float* sb = sbuf + col * SROW + (u0 - j * US);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(sb + g * US) = (u32x2){__float_as_uint(st[g][0]), __float_as_uint(st[g][UPW - 1])};
+        *reinterpret_cast<u32x2*>(sb + 4 * US) = (u32x2){__float_as_uint(c[mt][0]), __float_as_uint(c[mt][UPW - 1])};
+        *reinterpret_cast<u32x2*>(sb + 5 * US) = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[UPW - 1])};
+      }
+      if (XAHEAD && t + 1 < T) {
+        xraw(t + 1, 0, accx);
+        if (XLDS) {   // a thread reads back what it wrote itself
+          *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0];
+          *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[NR > 1 ? 1 : 0];
         }
       }
       STAMP(3);
@@ -637,21 +821,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // has long completed: left alone, the compiler waits for them with vmcnt(0) at their first use in
       // the next phase's gate math -- behind the prefetch loads issued just before it (HBM latency, ~1200
       // cycles on the critical path of every step).
+      if (FUSE) xstore(t + 2, mt, xl);   // (t + 2) & 1 == t & 1: x_t was read before this phase's first barrier
       if (STAGE) {
-        if (t + 1 < T) {   // the next step's pre-activations into the other pbuf half
+        if (!FUSE && t + 1 < T) {   // the next step's pre-activations into the other pbuf half
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg >> 2, g = seg & 3;
             *reinterpret_cast<f32x4*>(pbuf + ((t + 1) & 1) * 16 * PROW + r * PROW + g * US + c4 * 4) = pl[i];
           }
         }
-        float* sb = sbuf + col * SROW + (u0 - j * US);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<u32x2*>(sb + g * US) = (u32x2){__float_as_uint(st[g][0]), __float_as_uint(st[g][UPW - 1])};
-        *reinterpret_cast<u32x2*>(sb + 4 * US) = (u32x2){__float_as_uint(c[mt][0]), __float_as_uint(c[mt][UPW - 1])};
-        *reinterpret_cast<u32x2*>(sb + 5 * US) = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[UPW - 1])};
       }
-      if (!STAGE) {
+      if (!STAGE && !FUSE) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -675,10 +855,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           for (int u = 0; u < UPW; ++u) v[u] = c[mt][u];
           stgn<UPW, 0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, v);
         }
+        if (!FUSE) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int u = 0; u < UPW; ++u) pre[mt][g][u] = nxt[g][u];
+            for (int u = 0; u < UPW; ++u) pre[mt][g][u] = nxt[g][u];
+        }
       }
       STAMP(8);
       __syncthreads();   // the pulled tile is complete for its MFMA in the next phase
@@ -1079,6 +1261,7 @@ __global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int
 // ---- launch planning ---------------------------------------------------------------------
 struct Plan {
   int H, US, KS, MT;
+  int XK;              // forward: padded input width of the fused projection (32 / 64), 0 = projection by GEMM
   int NCL;
   int rows_per_cluster;
   int clusters_per_launch;
@@ -1089,7 +1272,18 @@ struct Plan {
 // forward kernel interleaves the tiles of a cluster, which hides a tile's hand-off under another tile's
 // compute -- 9 % faster than stepping them in lockstep at B = 1024 -- but two interleaved tiles on half the
 // CUs are still slower than one tile per cluster on all of them: 4.5 vs 3.4 us per step at B = 512.)
-bool make_plan(int H, int B, Plan& p, bool fwd = false) {
+// Forward launches of layers with a narrow input (in_dim <= 64, a multiple of 4; hidden <= 256) compute the input
+// projection inside the recurrent kernel.  The choice depends on (H, in_dim) only -- see lstm_fwd_kernel.
+int fused_xk(int H, int in_dim) {
+  // TB_FUSE_PROJ: bit mask of the hidden sizes that fuse (1: <= 64, 2: 128, 4: 256; 0 = never)
+  static const int mask = []() { const char* e = getenv("TB_FUSE_PROJ"); return e ? atoi(e) : 7; }();
+  if (!(mask & (H <= 64 ? 1 : (H == 128 ? 2 : 4)))) return 0;
+  if (H > 256 || in_dim <= 0 || in_dim > 64 || (in_dim & 3)) return 0;
+  if (H == 256 && in_dim > 32) return 0;   // 268 registers: would break the two-launches-per-CU rule of make_plan
+  return in_dim <= 32 ? 32 : 64;
+}
+
+bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   int US, KS;
   switch (H) {
     case 16: US = 16; KS = 1; break;
@@ -1101,6 +1295,8 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
     default: return false;
   }
   p.H = H; p.US = US; p.KS = KS; p.NCL = H / US;
+  const int XK = fwd ? fused_xk(H, in_dim) : 0;
+  p.XK = XK;
   const int cus = tb_num_cus();
   const int max_clusters = cus / p.NCL > 0 ? cus / p.NCL : 1;
   int MT = 1;
@@ -1115,8 +1311,10 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   const int NCL = p.NCL;
   auto lds_f = [=](int mt) {
     size_t b = ((size_t)mt * 16 * (HK + 8) + (size_t)(KS > 1 ? NUG * KS * (KS - 1) * 256 * (4 / KS) : 0)) * 4 + 16;
-    if (mt == 1 && NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8], sbuf [16][6*US+8]
-      b += ((size_t)2 * 16 * (4 * US + 8) + (size_t)16 * (6 * US + 8)) * 4;
+    if (mt == 1 && NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8] (not fused), sbuf [16][6*US+8]
+      b += ((size_t)(XK ? 0 : 2 * 16 * (4 * US + 8)) + (size_t)16 * (6 * US + 8)) * 4;
+    if (XK)   // W_ih rows [4*US][XK+8] and x tiles [2][mt*16][XK+8], bf16 hi and lo each
+      b += ((size_t)4 * US + (size_t)2 * mt * 16) * (XK + 8) * 2 * 2 + (size_t)4 * US * 4 + (H >= 256 && mt == 1 ? 256 * 8 * 4 : 0);
     return b;
   };
   auto lds_b = [=](int mt) { return ((size_t)mt * 16 * (4 * US + 8) + (size_t)mt * 16 * (H + 4) + 4096) * 4 + 16; };
@@ -1144,15 +1342,15 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false) {
   return true;
 }
 
-template <int H, int US, int KS, int MT>
+template <int H, int US, int KS, int MT, int XK>
 int launch_fwd_t(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, US, KS, MT>),
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, US, KS, MT, XK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, US, KS, MT>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, US, KS, MT, XK>), dim3(grid), dim3(256), lds, s, a);
   TB_LAUNCH_CHECK("lstm_fwd_kernel");
   return TB_OK;
 }
@@ -1170,8 +1368,19 @@ int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
   return TB_OK;
 }
 
-#define FWD_CASE(h, us, ks, mt) \
-  if (p.H == h && p.MT == mt) return launch_fwd_t<h, us, ks, mt>(a, grid, p.lds_fwd, s)
+#define FWD_CASE(h, us, ks, mt)                                                       \
+  if (p.H == h && p.MT == mt) {                                                       \
+    if (p.XK == 32) return launch_fwd_t<h, us, ks, mt, 32>(a, grid, p.lds_fwd, s);    \
+    if (p.XK == 64) return launch_fwd_t<h, us, ks, mt, 64>(a, grid, p.lds_fwd, s);    \
+    return launch_fwd_t<h, us, ks, mt, 0>(a, grid, p.lds_fwd, s);                     \
+  }
+#define FWD_CASE32(h, us, ks, mt)                                                     \
+  if (p.H == h && p.MT == mt) {                                                       \
+    if (p.XK == 32) return launch_fwd_t<h, us, ks, mt, 32>(a, grid, p.lds_fwd, s);    \
+    if (p.XK == 0) return launch_fwd_t<h, us, ks, mt, 0>(a, grid, p.lds_fwd, s);      \
+  }
+#define FWD_CASE0(h, us, ks, mt) \
+  if (p.H == h && p.MT == mt) return launch_fwd_t<h, us, ks, mt, 0>(a, grid, p.lds_fwd, s)
 #define BWD_CASE(h, us, mt) \
   if (p.H == h && p.MT == mt) return launch_bwd_t<h, us, mt>(a, grid, p.lds_bwd, s)
 
@@ -1180,8 +1389,8 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(32, 32, 1, 1); FWD_CASE(32, 32, 1, 2); FWD_CASE(32, 32, 1, 4);
   FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
-  FWD_CASE(256, 32, 2, 1); FWD_CASE(256, 32, 2, 2);
-  FWD_CASE(512, 16, 4, 1); FWD_CASE(512, 16, 4, 2);
+  FWD_CASE32(256, 32, 2, 1); FWD_CASE32(256, 32, 2, 2);
+  FWD_CASE0(512, 16, 4, 1); FWD_CASE0(512, 16, 4, 2);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }
 
@@ -1253,20 +1462,25 @@ static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, c
                          void* ws, size_t ws_bytes, int* err, void* stream, bool prof) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
-  if (!x || !w_ih || !w_hh || !y || !gates || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
+  if (!x || !w_ih || !w_hh || !y || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
   if (reinterpret_cast<uintptr_t>(ws) & 255) return tb_set_error(TB_ERR_ARG, "lstm_fwd: the workspace must be 256-byte aligned");
   if (train && !cstash) return tb_set_error(TB_ERR_ARG, "lstm_fwd: train needs a cell stash");
   Plan p;
-  if (!make_plan(H, B, p, true))
+  if (!make_plan(H, B, p, true, in_dim))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d not supported (16,32,64,128,256,512)", H);
+  // the gate buffer: projection output + BPTT stash; not touched by a fused inference launch
+  if (!gates && (train || !p.XK)) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null gate buffer");
   Carve c;
   const size_t need = carve(p, B, H, in_dim, false, static_cast<char*>(ws), ws_bytes, &c);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_fwd: workspace %zu < %zu", ws_bytes, need);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: T*H too large (%d x %d)", T, H);
   // P = x.W_ih^T + (b_ih + b_hh), written straight into the gate stash (the GEMM epilogue sums the two
   // bias vectors first, then adds)
-  int rc = tb_gemm_launch2(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, b_ih, b_hh, B * T, 4 * H, in_dim, 0, 0, 1,
-                           nullptr, 0, s, 0);
+  // -- unless the layer's input is narrow enough for the recurrent kernel to do it itself (Plan::XK)
+  int rc = TB_OK;
+  if (!p.XK)
+    rc = tb_gemm_launch2(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, b_ih, b_hh, B * T, 4 * H, in_dim, 0, 0, 1,
+                         nullptr, 0, s, 0);
   if (rc) return rc;
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   // algorithmic bytes of one layer forward: read x, write h, write the 5h stash
@@ -1274,6 +1488,7 @@ static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, c
     const int ncl = (ncl_total - c0) < p.clusters_per_launch ? (ncl_total - c0) : p.clusters_per_launch;
     FwdArgs a;
     a.P = gates; a.Whh = w_hh; a.y = y; a.cst = cstash;
+    a.x = x; a.Wih = w_ih; a.b_ih = b_ih; a.b_hh = b_hh; a.in_dim = in_dim;
     a.ring = c.X;
     a.hello = c.hello;
     a.epoch = next_epoch();
@@ -1305,7 +1520,7 @@ int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
 size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
   (void)T;
   Plan p;
-  if (!make_plan(H, B, p, backward == 0)) return 0;
+  if (!make_plan(H, B, p, backward == 0, in_dim)) return 0;
   return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
 }
 
@@ -1338,7 +1553,7 @@ int tb_lstm_fwd_static(const float* x, const float* w_ih, const float* w_hh, con
                        int* err, void* stream) {
   if (B <= 0 || T <= 0) return TB_OK;
   Plan p;
-  if (!make_plan(H, B, p, true))
+  if (!make_plan(H, B, p, true, in_dim))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd_static: hidden size %d not supported (16,32,64,128,256,512)", H);
   const size_t need = carve(p, B, H, in_dim, false, nullptr, 0, nullptr);
   if (need > kStaticScratchBytes)
