@@ -371,9 +371,27 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       }
       tb_split8(v0, v1, whi[g][s], wlo[g][s]);
     }
+  // W_ih fragments: in LDS for the clustered variants (no registers to spare: two of their launches must fit a CU),
+  // in registers like W_hh for single-workgroup layers (re-reading them every step would put 40-80 KB per step
+  // through the CU's LDS port: +0.3 us on a 1.1 us step)
+  constexpr bool WREG = FUSE && NCL == 1;
+  bf16x8 wxh[WREG ? 4 : 1][WREG ? NXS : 1], wxl[WREG ? 4 : 1][WREG ? NXS : 1];
+  if (WREG) {
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wih, 0, 4 * H * in * 4, kBufFlags);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int sx = 0; sx < NXS; ++sx) {
+        const int k0 = sx * 32 + q * 8;
+        const long o = (long)(g * H + uw) * in + k0;
+        const f32x4 v0 = ldg4<0>(rW, (active && k0 < in) ? o : 0x1FFFFFFFl);
+        const f32x4 v1 = ldg4<0>(rW, (active && k0 + 4 < in) ? o + 4 : 0x1FFFFFFFl);
+        tb_split8(v0, v1, wxh[WREG ? g : 0][WREG ? sx : 0], wxl[WREG ? g : 0][WREG ? sx : 0]);
+      }
+  }
   if (FUSE) {
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)a.Wih, 0, 4 * H * in * 4, kBufFlags);
-    for (int i = tid; i < 4 * US * (XK / 4); i += 256) {
+    for (int i = tid; i < (WREG ? 0 : 4 * US * (XK / 4)); i += 256) {
       const int row = i / (XK / 4), c4 = (i % (XK / 4)) * 4, g = row / US, r = row % US;
       const f32x4 v = ldg4<0>(rW, c4 < in ? (long)(g * H + j * US + r) * in + c4 : 0x1FFFFFFFl);
       u32x2 sh, sl;
@@ -452,9 +470,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
               bf16x8 ah[4], al[4];
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                const int wo = (g * US + ug * 16 + col) * LDX + sx * 32 + q * 8 + opq;
-                ah[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiH + wo));
-                al[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiL + wo));
+                if (WREG) {
+                  ah[g] = wxh[WREG ? g : 0][WREG ? sx : 0];
+                  al[g] = wxl[WREG ? g : 0][WREG ? sx : 0];
+                } else {
+                  const int wo = (g * US + ug * 16 + col) * LDX + sx * 32 + q * 8 + opq;
+                  ah[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiH + wo));
+                  al[g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wiL + wo));
+                }
               }
 #pragma unroll
               for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[g], bl, acc[g], 0, 0, 0);
@@ -502,15 +525,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // One tile per cluster: the x part of step t+1 is computed in the shadow of step t's hand-off (after the publish,
   // before the poll) into the accumulators that the next MFMA block continues from -- the same operations in the same
   // order as in the variants that do it at the top of the MFMA block, so the same bits.
-  constexpr bool XAHEAD = FUSE && MT == 1 && NCL > 1;
+  // Single-workgroup layers (NCL == 1) have no hand-off, but the matrix pipe idles during the gate math: there the x
+  // part of a tile's next step is issued in front of the gate math of its current one, for every tile.
+  constexpr bool XAHEAD = FUSE && (MT == 1 || NCL == 1);
   // Hidden 256 has no registers left to carry that across the pull (256 per lane is the co-residency limit): there the
   // two accumulators wait in LDS.
   constexpr bool XLDS = XAHEAD && H >= 256 && DEAL;
-  f32x4 accx[NR];
-  if (XAHEAD) xraw(0, 0, accx);
+  f32x4 accx[XAHEAD ? MT : 1][NR];
+  if (XAHEAD) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xraw(0, mt, accx[mt]);
+  }
   if (XLDS) {
-    *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0];
-    *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[NR > 1 ? 1 : 0];
+    *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0][0];
+    *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[0][NR > 1 ? 1 : 0];
   }   // the handshake's barriers above made the W_ih rows and x_0 visible
   STAMP_DECL;
 #ifdef TB_STAMPS
@@ -585,12 +613,13 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (FUSE) {
-        if (!XAHEAD) xraw(t, mt, accx);
+        const int am = XAHEAD ? mt : 0;
+        if (!XAHEAD) xraw(t, mt, accx[0]);
         if (XLDS) {
-          accx[0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8);
-          accx[NR > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8 + 4);
+          accx[0][0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8);
+          accx[0][NR > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8 + 4);
         }
-        xdeal(accx, acc);
+        xdeal(accx[am], acc);
       }
       if ((FUSE || t > 0) && active) {
         if (!FUSE || t > 0) {
@@ -682,6 +711,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
             }
           }
         }
+        // single-workgroup layers: the matrix pipe works on this tile's next x part while the VALU does the gate math
+        if (XAHEAD && NCL == 1 && t + 1 < T) xraw(t + 1, mt, accx[XAHEAD ? mt : 0]);
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
           const float ig = fsig(z[0][u]), fg = fsig(z[1][u]), gg = ftanh(z[2][u]), og = fsig(z[3][u]);
@@ -743,11 +774,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         *reinterpret_cast<u32x2*>(sb + 4 * US) = (u32x2){__float_as_uint(c[mt][0]), __float_as_uint(c[mt][UPW - 1])};
         *reinterpret_cast<u32x2*>(sb + 5 * US) = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[UPW - 1])};
       }
-      if (XAHEAD && t + 1 < T) {
-        xraw(t + 1, 0, accx);
+      if (XAHEAD && NCL > 1 && t + 1 < T) {
+        xraw(t + 1, 0, accx[0]);
         if (XLDS) {   // a thread reads back what it wrote itself
-          *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0];
-          *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[NR > 1 ? 1 : 0];
+          *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0][0];
+          *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[0][NR > 1 ? 1 : 0];
         }
       }
       STAMP(3);
