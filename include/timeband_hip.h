@@ -40,7 +40,9 @@ int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host, double* 
  *   x (B,T,in)  w_ih (4H,in)  w_hh (4H,H)  b_ih,b_hh (4H)  gate order i,f,g,o
  * forward : y (B,T,H).  `gates` (B,T,4H) receives the activated gates and `cstash` (B,T,H) the
  *           cell states when train != 0 (the BPTT stash); with train == 0 `gates` is scratch and
- *           cstash may be NULL.
+ *           cstash may be NULL.  For in_dim <= 64, a multiple of 4 (<= 32 at H = 256), the input
+ *           projection is computed inside the recurrent kernel: `gates` is then output only and may be
+ *           NULL with train == 0 (TB_FUSE_PROJ=0 in the environment: projection by GEMM for every shape).
  * backward: dy (B,T,H) -> dx (B,T,in) [nullable], dw_ih, dw_hh, db_ih, db_hh [each nullable];
  *           `gates` is consumed (overwritten with the pre-activation gradients).
  *           accumulate != 0: the four parameter gradients are ADDED to what the buffers hold (what
