@@ -337,7 +337,7 @@ def test_overlapped_iteration_equals_single_stream(dev):
     import bench
     cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
     results = []
-    for mask in (5, 0, 1, 2, 4, 7):
+    for mask in (5, 0, 1, 2, 4, 7, 13, 15):
         np.random.seed(3)
         ds, trainset, trainer = bench.build(cfg, dev)
         trainer.overlap, trainer.overlap_mask = mask != 0, mask

@@ -21,6 +21,19 @@ int tb_set_error(int code, const char* fmt, ...);
 int tb_check_hip(hipError_t e, const char* what);
 int tb_num_cus();
 size_t tb_gemm_ws_bytes();   // gemm.hip: upper bound of the split-K slabs
+// A product whose split-K reduction (and / or `C +=`) is left to the caller: C (+)= sum over z < splits of
+// slab[z][M][N], in that order.  splits == 0: nothing pending (the kernel wrote C itself).
+struct TbGemmDeferred {
+  const float* slab;
+  int splits, M, N, accumulate;
+  float* C;
+  long ldc;
+};
+// tb_gemm_launch without its reduction kernels (no bias / activation); falls back to the complete product
+// (d->splits = 0) where the operands have to be cut (> 2 GiB).
+int tb_gemm_launch_deferred(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C, long ldc,
+                            int M, int N, int K, int b_shift, int b_period, float* ws, size_t ws_bytes, hipStream_t stream,
+                            int accumulate, TbGemmDeferred* d);
 
 #define TB_HIP(call)                                   \
   do {                                                 \

@@ -472,7 +472,28 @@ int tb_gemm_launch(const float* A, long lda, int transA, const float* B, long ld
 
 static int gemm_launch_one(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                            long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
-                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate);
+                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate,
+                           TbGemmDeferred* defer = nullptr);
+
+static bool gemm_fits(const float*, long lda, int transA, long ldb, int transB, int M, int N, int K) {
+  constexpr long long kLimit = 0x7FFFFFF0ll / 4;   // floats
+  const long long exA = transA ? (long long)(K - 1) * lda + M : (long long)(M - 1) * lda + K;
+  const long long exB = transB ? (long long)(K - 1) * ldb + N : (long long)(N - 1) * ldb + K;
+  return exA < kLimit && exB < kLimit;
+}
+
+int tb_gemm_launch_deferred(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C, long ldc,
+                            int M, int N, int K, int b_shift, int b_period, float* ws, size_t ws_bytes, hipStream_t stream,
+                            int accumulate, TbGemmDeferred* d) {
+  d->splits = 0;
+  if (M <= 0 || N <= 0) return TB_OK;
+  if (K <= 0) return tb_set_error(TB_ERR_ARG, "gemm: K must be positive");
+  if (!gemm_fits(A, lda, transA, ldb, transB, M, N, K))
+    return tb_gemm_launch2(A, lda, transA, B, ldb, transB, C, ldc, nullptr, nullptr, M, N, K, 0, b_shift, b_period, ws,
+                           ws_bytes, stream, accumulate);
+  return gemm_launch_one(A, lda, transA, B, ldb, transB, C, ldc, nullptr, nullptr, M, N, K, 0, b_shift, b_period, ws,
+                         ws_bytes, stream, accumulate, d);
+}
 
 // bias2: optional second bias vector; the epilogue adds (bias + bias2), the two summed first.
 // The kernel addresses A and B through 32-bit buffer offsets (2 GiB each).  Larger operands -- the long-context
@@ -526,7 +547,8 @@ int tb_gemm_launch2(const float* A, long lda, int transA, const float* B, long l
 
 static int gemm_launch_one(const float* A, long lda, int transA, const float* B, long ldb, int transB, float* C,
                            long ldc, const float* bias, const float* bias2, int M, int N, int K, int act, int b_shift,
-                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate) {
+                           int b_period, float* ws, size_t ws_bytes, hipStream_t stream, int accumulate,
+                           TbGemmDeferred* defer) {
   if (M <= 0 || N <= 0) return TB_OK;
   if (accumulate && (!ws || ws_bytes < (size_t)M * N * sizeof(float)))
     return tb_set_error(TB_ERR_WORKSPACE, "gemm: accumulate needs a workspace of M x N floats");
@@ -583,6 +605,12 @@ static int gemm_launch_one(const float* A, long lda, int transA, const float* B,
   else if (cfg == 1) launch_cfg<256, 64, 4, 1>(a, transA, transB, grid, stream);
   else launch_cfg<128, 128, 2, 2>(a, transA, transB, grid, stream);
   TB_LAUNCH_CHECK("gemm_bf16x3_kernel");
+  if (defer && (splits > 1 || accumulate)) {   // the caller sums the slabs (and adds to C) in a kernel of its own
+    defer->slab = ws; defer->splits = splits; defer->M = M; defer->N = N; defer->accumulate = accumulate;
+    defer->C = Cout; defer->ldc = ldout;
+    tb_prof_end(TB_K_GEMM, stream);
+    return TB_OK;
+  }
   if (splits > 1) {
     const long total = (long)M * N;
     int zstep = 1;

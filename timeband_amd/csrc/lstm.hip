@@ -1278,6 +1278,101 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   }
 }
 
+// The tail of a layer's backward in one launch: both weight-gradient products' split-K sums (fixed order: bitwise
+// reproducible) with their `+=` into the gradient buffers, and the bias gradients from the per-cluster partials --
+// instead of two reduction kernels per product and one for the bias (7 small launches per layer backward, each with
+// its gap, in front of the next layer's BPTT kernel).
+struct WFinishArgs {
+  TbGemmDeferred g[2];
+  const float* dbpart;
+  int nparts, nb;
+  float* db_ih;
+  float* db_hh;
+  int db_acc;
+};
+
+__global__ void wgrad_finish_kernel(WFinishArgs f) {
+  const long n0 = f.g[0].splits ? (long)f.g[0].M * f.g[0].N : 0, n1 = f.g[1].splits ? (long)f.g[1].M * f.g[1].N : 0;
+  const long total = n0 + n1 + f.nb;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < n0 + n1) {
+      const TbGemmDeferred& g = i < n0 ? f.g[0] : f.g[1];
+      const long e = i < n0 ? i : i - n0, n = i < n0 ? n0 : n1;
+      float s = 0.f;
+      for (int z = 0; z < g.splits; ++z) s += g.slab[(size_t)z * n + e];
+      float* c = g.C + (e / g.N) * g.ldc + e % g.N;
+      *c = g.accumulate ? *c + s : s;
+    } else {
+      const int k = (int)(i - n0 - n1);
+      float s = 0.f;
+      for (int p = 0; p < f.nparts; ++p) s += f.dbpart[(size_t)p * f.nb + k];
+      if (f.db_ih) f.db_ih[k] = f.db_acc ? f.db_ih[k] + s : s;
+      if (f.db_hh) f.db_hh[k] = f.db_acc ? f.db_hh[k] + s : s;
+    }
+  }
+}
+
+// the same, 4 elements per thread (16-byte loads, 8 slabs in flight): every N, ldc and pointer a multiple of 4 / 16
+// Four neighbouring lanes share one group of 4 elements: lane p sums the slabs z = p, p + 4, ..., the four partial sums
+// meet in two butterfly steps (a fixed order: bitwise reproducible).
+__global__ void wgrad_finish4_kernel(WFinishArgs f) {
+  const long q0 = f.g[0].splits ? (long)f.g[0].M * f.g[0].N / 4 : 0, q1 = f.g[1].splits ? (long)f.g[1].M * f.g[1].N / 4 : 0;
+  const long total = (q0 + q1) * 4 + f.nb;    // a multiple of 4 lanes per element group: no group straddles a wave
+  const long iters = (total + (long)gridDim.x * blockDim.x - 1) / ((long)gridDim.x * blockDim.x);
+  for (long it = 0; it < iters; ++it) {       // uniform trip count: the butterfly needs all four lanes of a group
+    const long i = it * (long)gridDim.x * blockDim.x + blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < (q0 + q1) * 4) {
+      const long eg = i >> 2;
+      const int part = (int)(i & 3);
+      const TbGemmDeferred& g = eg < q0 ? f.g[0] : f.g[1];
+      const long e = eg < q0 ? eg : eg - q0, n4 = eg < q0 ? q0 : q1;
+      const f32x4* sl = reinterpret_cast<const f32x4*>(g.slab) + e;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      int z = part;
+      for (; z + 12 < g.splits; z += 16) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = sl[(size_t)(z + 4 * k) * n4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += v[k];
+      }
+      for (; z < g.splits; z += 4) s += sl[(size_t)z * n4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], 2);
+      if (part == 0) {
+        const long el = e * 4;
+        f32x4* c = reinterpret_cast<f32x4*>(g.C + (el / g.N) * g.ldc + el % g.N);
+        *c = g.accumulate ? *c + s : s;
+      }
+    } else if (i < total) {
+      const int k = (int)(i - (q0 + q1) * 4);
+      float s = 0.f;
+      for (int p = 0; p < f.nparts; ++p) s += f.dbpart[(size_t)p * f.nb + k];
+      if (f.db_ih) f.db_ih[k] = f.db_acc ? f.db_ih[k] + s : s;
+      if (f.db_hh) f.db_hh[k] = f.db_acc ? f.db_hh[k] + s : s;
+    }
+  }
+}
+
+int launch_wgrad_finish(const WFinishArgs& f, hipStream_t s) {
+  const long n0 = f.g[0].splits ? (long)f.g[0].M * f.g[0].N : 0, n1 = f.g[1].splits ? (long)f.g[1].M * f.g[1].N : 0;
+  if (n0 + n1 + f.nb <= 0) return TB_OK;
+  bool vec = true;
+  for (int k = 0; k < 2; ++k)
+    if (f.g[k].splits && ((f.g[k].N & 3) || (f.g[k].ldc & 3) || (reinterpret_cast<uintptr_t>(f.g[k].slab) & 15) ||
+                          (reinterpret_cast<uintptr_t>(f.g[k].C) & 15)))
+      vec = false;
+  const long total = n0 + n1 + f.nb;   // vectorised: 4 lanes per group of 4 elements -- the same count
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (vec) hipLaunchKernelGGL(wgrad_finish4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f);
+  else hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, s, f);
+  TB_LAUNCH_CHECK("wgrad_finish_kernel");
+  return TB_OK;
+}
+
 __global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* db_ih, float* db_hh,
                                  int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1458,7 +1553,8 @@ struct Carve {
   unsigned long long* hello; size_t hello_bytes;
   float* X; size_t x_bytes;
   float* dbpart;
-  float* gemm_ws; size_t gemm_ws_bytes;
+  float* gemm_ws; size_t gemm_ws_bytes;     // two regions of gemm_ws_bytes each (backward): the two weight-gradient
+  float* gemm_ws2;                          // products keep their slabs until the common finish kernel
 };
 
 size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
@@ -1471,7 +1567,7 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * (16 * p.MT) * H * sizeof(float), 256) : 0;
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
   (void)in_dim;
-  const size_t gemm_bytes = bwd ? tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
+  const size_t gemm_bytes = bwd ? 2 * tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
   if (c) { c->hello = reinterpret_cast<unsigned long long*>(base + off); c->hello_bytes = hello_bytes; }
   off += hello_bytes;
   if (c) { c->X = reinterpret_cast<float*>(base + off); c->x_bytes = x_bytes; }
@@ -1480,7 +1576,8 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   off += dbpart_bytes;
   if (c) {
     c->gemm_ws = reinterpret_cast<float*>(base + off);
-    c->gemm_ws_bytes = total > off ? total - off : 0;
+    c->gemm_ws_bytes = total > off ? (total - off) / 2 / 256 * 256 : 0;
+    c->gemm_ws2 = reinterpret_cast<float*>(base + off + c->gemm_ws_bytes);
   }
   off += gemm_bytes;
   return off;
@@ -1636,33 +1733,33 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
     if (rc) return rc;
   }
   tb_prof_end(TB_K_LSTM_BWD, s);
-  if (db_ih || db_hh) {
-    hipLaunchKernelGGL(db_reduce_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, s, c.dbpart, ncl_total, 4 * H,
-                       db_ih, db_hh, accumulate);
-    TB_LAUNCH_CHECK("db_reduce_kernel");
-  }
   const int M = B * T;
-  if (dx) {   // dx = dG . W_ih            [M,4H].[4H,in]
+  if (dx) {   // dx = dG . W_ih            [M,4H].[4H,in]   (first: the layer below waits for it)
     rc = tb_gemm_launch(gates, 4L * H, 0, w_ih, in_dim, 1, dx, in_dim, nullptr, M, in_dim, 4 * H, 0, 0, 1,
                         c.gemm_ws, c.gemm_ws_bytes, s, 0);
     if (rc) return rc;
   }
+  WFinishArgs f;
+  f.g[0].splits = f.g[1].splits = 0;
   if (dw_ih) {  // dW_ih = dG^T . x        [4H,M].[M,in]
-    rc = tb_gemm_launch(gates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, nullptr, 4 * H, in_dim, M, 0, 0, 1,
-                        c.gemm_ws, c.gemm_ws_bytes, s, accumulate);
+    rc = tb_gemm_launch_deferred(gates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, 4 * H, in_dim, M, 0, 1, c.gemm_ws,
+                                 c.gemm_ws_bytes, s, accumulate, &f.g[0]);
     if (rc) return rc;
   }
   if (dw_hh) {  // dW_hh = dG^T . h_prev,  h_prev[b,t] = y[b,t-1], 0 at t = 0
-    rc = tb_gemm_launch(gates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, c.gemm_ws,
-                        c.gemm_ws_bytes, s, accumulate);
+    rc = tb_gemm_launch_deferred(gates, 4L * H, 1, y, H, 1, dw_hh, H, 4 * H, H, M, 1, T, c.gemm_ws2, c.gemm_ws_bytes, s,
+                                 accumulate, &f.g[1]);
     if (rc) return rc;
   }
-  return TB_OK;
+  const bool db = db_ih || db_hh;
+  f.dbpart = c.dbpart; f.nparts = ncl_total; f.nb = db ? 4 * H : 0;
+  f.db_ih = db_ih; f.db_hh = db_hh; f.db_acc = accumulate;
+  return launch_wgrad_finish(f, s);
 }
 
 size_t tb_lstm_wgrad_workspace_bytes(int in_dim, int H) {
   (void)in_dim; (void)H;
-  return tb_align_up(tb_gemm_ws_bytes(), 256);
+  return 2 * tb_align_up(tb_gemm_ws_bytes(), 256);
 }
 
 // The two weight-gradient products of tb_lstm_bwd on their own: dW_ih = dG^T.x, dW_hh = dG^T.h_prev.  A caller
@@ -1677,17 +1774,21 @@ int tb_lstm_wgrad(const float* x, const float* y, const float* dgates, float* dw
   if (ws_bytes < tb_lstm_wgrad_workspace_bytes(in_dim, H)) return tb_set_error(TB_ERR_WORKSPACE, "lstm_wgrad: workspace too small");
   const int M = B * T;
   int rc;
+  const size_t half = ws_bytes / 2 / 256 * 256;
+  WFinishArgs f;
+  f.g[0].splits = f.g[1].splits = 0;
   if (dw_ih) {
-    rc = tb_gemm_launch(dgates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, nullptr, 4 * H, in_dim, M, 0, 0, 1,
-                        static_cast<float*>(ws), ws_bytes, s, accumulate);
+    rc = tb_gemm_launch_deferred(dgates, 4L * H, 1, x, in_dim, 1, dw_ih, in_dim, 4 * H, in_dim, M, 0, 1,
+                                 static_cast<float*>(ws), half, s, accumulate, &f.g[0]);
     if (rc) return rc;
   }
   if (dw_hh) {
-    rc = tb_gemm_launch(dgates, 4L * H, 1, y, H, 1, dw_hh, H, nullptr, 4 * H, H, M, 0, 1, T, static_cast<float*>(ws),
-                        ws_bytes, s, accumulate);
+    rc = tb_gemm_launch_deferred(dgates, 4L * H, 1, y, H, 1, dw_hh, H, 4 * H, H, M, 1, T,
+                                 reinterpret_cast<float*>(static_cast<char*>(ws) + half), half, s, accumulate, &f.g[1]);
     if (rc) return rc;
   }
-  return TB_OK;
+  f.dbpart = nullptr; f.nparts = 0; f.nb = 0; f.db_ih = f.db_hh = nullptr; f.db_acc = 0;
+  return launch_wgrad_finish(f, s);
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@ source/trainer.py:95-98 -- Adam re-created every epoch; :143-144 -- RMSprop re-c
 buffer, so an optimizer step is one kernel launch and a data-parallel gradient exchange is one
 all-reduce with no packing.  Stock torch.optim optimizers still work on the same parameters.
 """
+import contextlib
 import os
 
 import torch
@@ -67,6 +68,29 @@ class FlatParams:
             for p in b["params"]:
                 p._tb_bucket = i
         return buckets
+
+    @contextlib.contextmanager
+    def alt(self):
+        """Backward passes enqueued inside add their parameter gradients into a SECOND buffer (`grad2`, zero between
+        uses) instead of `grad`: two backward passes of one network can then run on two streams at once.  merge_alt()
+        adds it in: (0 + g1) + (0 + g2) -- the same two-term sum, bit for bit, as accumulating g2 onto g1."""
+        if getattr(self, "grad2", None) is None:
+            self.grad2 = torch.zeros_like(self.grad)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            p._tb_grad_slot = self.grad2[off:off + k].view(p.shape)
+            off += k
+        try:
+            yield
+        finally:
+            for p in self.params:
+                p._tb_grad_slot = p.grad
+
+    def merge_alt(self):
+        if getattr(self, "grad2", None) is not None:
+            self.grad.add_(self.grad2)
+            self.grad2.zero_()
 
     def check(self):
         """Parameters / grads must still alias the flat buffers (e.g. nobody set .grad = None)."""

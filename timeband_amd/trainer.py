@@ -149,7 +149,10 @@ class TIMEBANDTrainer:
         # critic step, 2 = G-phase generator forward under the D-phase backward, 4 = graph cut at fake_y
         # (the generator's share of errD.backward() runs on the stream of its forward -- the side stream
         # with bit 1 -- under the G phase's forward and discriminator pass)
-        ov1, ov2, ov4 = ((overlap and bool(self.overlap_mask & b)) for b in (1, 2, 4))
+        # 8 (needs 4) = the generator's two backward passes at once: the G-phase one adds into a second gradient buffer
+        # (optim.FlatParams.alt), merged before the step -- the same two-term sum bit for bit
+        ov1, ov2, ov4, ov8 = ((overlap and bool(self.overlap_mask & b)) for b in (1, 2, 4, 8))
+        ov8 = ov8 and ov4
         share = self.share_gpass and training
         if share:
             ov2 = False
@@ -247,6 +250,13 @@ class TIMEBANDTrainer:
                     if overlap:
                         main.wait_stream(s1)
                         main.wait_stream(s2)
+                elif ov4 and ov8:   # G-phase generator backward BESIDE the D-phase one, into the second gradient buffer
+                    s2.wait_stream(main)
+                    with torch.cuda.stream(s2), self.optimG.flat.alt():
+                        fake_g.backward(fake_y.grad)
+                    main.wait_stream(s1)
+                    main.wait_stream(s2)
+                    self.optimG.flat.merge_alt()
                 elif ov4:    # G-phase generator backward after the D-phase one (both add into G's gradients)
                     s2.wait_stream(main)
                     s2.wait_stream(s1)
