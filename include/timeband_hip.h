@@ -51,6 +51,10 @@ int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host, double* 
  * H must be one of 16,32,64,128,256,512 (tb_lstm_supported).  `err` is a device int[4]: err[0]
  * becomes non-zero if an inter-workgroup wait timed out (results are then invalid). */
 int tb_lstm_supported(int H);
+/* 1 if this shape's launch is EXCLUSIVE: its workgroups leave no room for a second clustered LSTM workgroup on a CU
+ * (BPTT at H = 256 with B > 512 on 256 CUs), so no other tb_lstm_fwd / tb_lstm_bwd launch with H > 64 may be in flight
+ * on another stream while it runs (two half-resident launches would wait for each other until the 2 s timeout). */
+int tb_lstm_exclusive(int B, int in_dim, int H, int backward);
 size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward);
 int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                 float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,

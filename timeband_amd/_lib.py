@@ -29,6 +29,7 @@ SIGNATURES = {
     "tb_prof_enable": (I, [I, I]),
     "tb_prof_read": (I, [I, C.POINTER(I), C.POINTER(D), C.POINTER(D)]),
     "tb_lstm_supported": (I, [I]),
+    "tb_lstm_exclusive": (I, [I, I, I, I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
     "tb_lstm_wgrad_workspace_bytes": (Z, [I, I]),

@@ -1420,6 +1420,14 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
     case 512: US = 16; KS = 4; break;
     default: return false;
   }
+  // BPTT at hidden 256 with more batch tiles than the 8-member layout has clusters (B > 512 on 256 CUs: the
+  // discriminator's real + fake pass): 4-member clusters, 64 units per member, W_hh^T on 256 registers.  A step costs
+  // more (4.3 against 2.8 us: twice the MFMA work per CU) but one launch covers 64 tiles instead of two launches of 32
+  // (0.55 against 0.75 ms at B = 1024).  Such a workgroup holds ~390 registers per lane, so NO second clustered
+  // workgroup fits beside it on a CU: the launch is EXCLUSIVE (tb_lstm_exclusive) -- the caller must not have another
+  // clustered launch in flight (the Python host orders it: ops.Runtime.clustered_begin).  TB_WIDE256=0 turns it off.
+  static const bool wide256 = []() { const char* e = getenv("TB_WIDE256"); return !e || atoi(e) != 0; }();
+  if (H == 256 && !fwd && wide256 && B > 16 * (tb_num_cus() / 8)) { US = 64; KS = 1; }
   p.H = H; p.US = US; p.KS = KS; p.NCL = H / US;
   const int XK = fwd ? fused_xk(H, in_dim) : 0;
   p.XK = XK;
@@ -1525,6 +1533,7 @@ int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
   BWD_CASE(32, 32, 1); BWD_CASE(32, 32, 2); BWD_CASE(32, 32, 4);
   BWD_CASE(64, 64, 1); BWD_CASE(64, 64, 2);
   BWD_CASE(128, 32, 1); BWD_CASE(128, 32, 2); BWD_CASE(128, 32, 4);
+  if (p.US == 64) { BWD_CASE(256, 64, 1); }
   BWD_CASE(256, 32, 1); BWD_CASE(256, 32, 2);
   BWD_CASE(512, 16, 1);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: no kernel for H=%d MT=%d", p.H, p.MT);
@@ -1650,6 +1659,12 @@ size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
   Plan p;
   if (!make_plan(H, B, p, backward == 0, in_dim)) return 0;
   return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
+}
+
+int tb_lstm_exclusive(int B, int in_dim, int H, int backward) {
+  Plan p;
+  if (!make_plan(H, B, p, backward == 0, in_dim)) return 0;
+  return (p.H == 256 && p.US == 64) ? 1 : 0;
 }
 
 int tb_lstm_supported(int H) {

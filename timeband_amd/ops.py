@@ -86,31 +86,35 @@ class Runtime:
     # clustered launch on stream S: of the OTHER streams with a clustered launch not yet known to be finished,
     # all but the most recent one are waited for by S (oldest first).  With the default streams every such wait
     # is on work S depends on anyway.
-    def clustered_begin(self):
+    # An EXCLUSIVE launch (tb_lstm_exclusive: workgroups of ~390 registers, nothing clustered fits beside them) waits
+    # for every other stream's clustered launch, and every later clustered launch elsewhere waits for it.
+    def clustered_begin(self, exclusive=False):
         cl = self.__dict__.setdefault("_clustered", {})
         if not cl:
             return
         cur = torch.cuda.current_stream(self.device)
         live = []
-        for key, (seq, ev) in list(cl.items()):
+        for key, (seq, ev, excl) in list(cl.items()):
             if key == cur.cuda_stream:
                 continue
             if ev.query():
                 del cl[key]
+            elif excl or exclusive:
+                cur.wait_event(ev)
             else:
                 live.append((seq, ev))
         live.sort(key=lambda q: q[0])
         for seq, ev in live[:-1]:
             cur.wait_event(ev)
 
-    def clustered_end(self):
+    def clustered_end(self, exclusive=False):
         cl = self.__dict__.setdefault("_clustered", {})
         cur = torch.cuda.current_stream(self.device)
         self._cl_seq = getattr(self, "_cl_seq", 0) + 1
         old = cl.get(cur.cuda_stream)
         ev = old[1] if old is not None else torch.cuda.Event()
         ev.record(cur)
-        cl[cur.cuda_stream] = (self._cl_seq, ev)
+        cl[cur.cuda_stream] = (self._cl_seq, ev, bool(exclusive))
 
     def check(self):
         """Host sync: raise if a persistent kernel reported an inter-workgroup wait timeout."""
@@ -216,13 +220,14 @@ class _LSTMLayerFn(torch.autograd.Function):
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 1)
         ws = rt.workspace(nws)
         side = slots is not None and Runtime.wgrad_overlap and (dw_ih is not None or dw_hh is not None)
+        excl = H > 64 and bool(lib.tb_lstm_exclusive(B, In, H, 1))
         if H > 64:
-            rt.clustered_begin()
+            rt.clustered_begin(excl)
         _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
                   _ptr(dx), _ptr(None if side else dw_ih), _ptr(None if side else dw_hh), _ptr(db_ih), _ptr(db_hh),
                   B, T, In, H, 1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
         if H > 64:
-            rt.clustered_end()
+            rt.clustered_end(excl)
         if side:
             cur = torch.cuda.current_stream(dev)
             wg = rt.wgrad_stream()
