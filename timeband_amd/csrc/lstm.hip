@@ -276,6 +276,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // written at the end of a step and flushed at the top of the next one, behind the barrier between them.
   constexpr bool STAGE = MT == 1 && NCL > 1 && KS == 2 && US == 32;
   constexpr int PROW = 4 * US + 8, SROW = 6 * US + 8;   // padded LDS rows: [4 gates][US], [4 gates, c, y][US]
+  // EMU2: the 4-member layout of hidden 256 (64 units per member, the whole k range in one wave) adds up in the order
+  // of the 8-member layout's two k-part waves -- two accumulator sets, one per k half, the x part dealt between them,
+  // joined as (own half + pre-activation) + other half with "own" by the unit's position -- so a window's result
+  // stays bit-identical whichever layout its batch gets.
+  constexpr bool EMU2 = H == 256 && US == 64 && KS == 1;
   constexpr bool FUSE = XK > 0;
   constexpr int NXS = XK / 32;                          // x k-steps
   constexpr int LDX = XK + 8;                           // LDS row stride of the W_ih / x tiles (bf16 elements)
@@ -609,9 +614,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         }
       }
       // (B) (W_hh . h_{t-1}^T) on the matrix cores (h_{-1} = 0: nothing to do at t = 0)
-      f32x4 acc[4];
+      f32x4 acc[4], acc2[EMU2 ? 4 : 1];
 #pragma unroll
       for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < (EMU2 ? 4 : 1); ++g) acc2[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (FUSE) {
         const int am = XAHEAD ? mt : 0;
         if (!XAHEAD) xraw(t, mt, accx[0]);
@@ -620,6 +627,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           accx[0][NR > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8 + 4);
         }
         xdeal(accx[am], acc);
+        if (EMU2 && NXS == 1) {   // the 8-member layout deals one x k-step by gate: 0, 2 to the low k half, 1, 3 to the high one
+          acc2[EMU2 ? 1 : 0] = acc[1]; acc2[EMU2 ? 3 : 0] = acc[3];
+          acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
       }
       if ((FUSE || t > 0) && active) {
         if (!FUSE || t > 0) {
@@ -629,6 +640,15 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(hiL + ho));
           const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(loL + ho));
           // three passes over the four independent accumulators: no MFMA waits on the one before it
+          if (EMU2 && s >= NKS / 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc2[EMU2 ? g : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bl, acc2[EMU2 ? g : 0], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc2[EMU2 ? g : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[g][s], bh, acc2[EMU2 ? g : 0], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc2[EMU2 ? g : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bh, acc2[EMU2 ? g : 0], 0, 0, 0);
+            continue;
+          }
 #pragma unroll
           for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi[g][s], bl, acc[g], 0, 0, 0);
 #pragma unroll
@@ -695,7 +715,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int u = 0; u < UPW; ++u) z[g][u] = acc[g][kp * UPW + u] + pre[mt][g][u];
+          for (int u = 0; u < UPW; ++u) {
+            if (EMU2) {   // units 0, 1 of a lane's four: finished by the low-k wave of the 8-member layout; 2, 3: by the high-k one
+              const float lo = acc[g][u], hi = acc2[EMU2 ? g : 0][u];
+              z[g][u] = u < 2 ? (lo + pre[mt][g][u]) + hi : (hi + pre[mt][g][u]) + lo;
+            } else {
+              z[g][u] = acc[g][kp * UPW + u] + pre[mt][g][u];
+            }
+          }
         if (KS > 1 && (FUSE || t > 0)) {
 #pragma unroll
           for (int sr = 0; sr < KS; ++sr) {
@@ -1427,7 +1454,7 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   // workgroup fits beside it on a CU: the launch is EXCLUSIVE (tb_lstm_exclusive) -- the caller must not have another
   // clustered launch in flight (the Python host orders it: ops.Runtime.clustered_begin).  TB_WIDE256=0 turns it off.
   static const bool wide256 = []() { const char* e = getenv("TB_WIDE256"); return !e || atoi(e) != 0; }();
-  if (H == 256 && !fwd && wide256 && B > 16 * (tb_num_cus() / 8)) { US = 64; KS = 1; }
+  if (H == 256 && wide256 && B > 16 * (tb_num_cus() / 8)) { US = 64; KS = 1; }
   p.H = H; p.US = US; p.KS = KS; p.NCL = H / US;
   const int XK = fwd ? fused_xk(H, in_dim) : 0;
   p.XK = XK;
@@ -1439,7 +1466,7 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   // the variants that can meet on a full-size batch stay within half a SIMD's registers (256), so two such
   // launches always fit side by side.  BPTT at H=256 with two tiles needs 288 and is no faster than two
   // one-tile launches (6.0 vs 2 x 2.9 us/step), hence the cap of 1 there.
-  const int mt_cap = fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4));
+  const int mt_cap = US == 64 && H == 256 ? 1 : (fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4)));
   const int NUG = US / 16;
   const int HK = H < 32 ? 32 : H;
   const int NCL = p.NCL;
@@ -1523,6 +1550,7 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(32, 32, 1, 1); FWD_CASE(32, 32, 1, 2); FWD_CASE(32, 32, 1, 4);
   FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
+  if (p.US == 64) { FWD_CASE32(256, 64, 1, 1); }
   FWD_CASE32(256, 32, 2, 1); FWD_CASE32(256, 32, 2, 2);
   FWD_CASE0(512, 16, 4, 1); FWD_CASE0(512, 16, 4, 2);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);

@@ -184,12 +184,13 @@ class _LSTMLayerFn(torch.autograd.Function):
         cst = torch.empty(B, T, H, dtype=torch.float32, device=x.device) if train else None
         nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 0)
         ws = rt.workspace(nws)
+        excl = H > 64 and bool(lib.tb_lstm_exclusive(B, In, H, 0))
         if H > 64:
-            rt.clustered_begin()
+            rt.clustered_begin(excl)
         _lib.call("tb_lstm_fwd", _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(y), _ptr(gates),
                   _ptr(cst), B, T, In, H, int(train), _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
         if H > 64:
-            rt.clustered_end()
+            rt.clustered_end(excl)
         if train:
             ctx.save_for_backward(x, w_ih, w_hh, y, gates, cst)
             ctx.dims = (B, T, In, H)
