@@ -152,6 +152,40 @@ def test_third_clustered_stream_is_held_back(dev):
         assert torch.equal(a, b)
 
 
+def test_exclusive_launch_is_ordered_against_other_streams(dev):
+    """Hidden 256 with 1024 rows runs on 4-member clusters whose workgroups fill a CU's registers (tb_lstm_exclusive):
+    queued beside clustered launches on two other streams, forward and backward, it must be ordered by ops.Runtime --
+    no wait timeout, and the bits of passes that run alone."""
+    from timeband_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.tb_lstm_exclusive(1024, 32, 256, 0) == 1 and lib.tb_lstm_exclusive(1024, 32, 256, 1) == 1
+    assert lib.tb_lstm_exclusive(512, 32, 256, 0) == 0 and lib.tb_lstm_exclusive(1024, 64, 128, 1) == 0
+    rng = np.random.default_rng(14)
+    Tn, In, H = 24, 32, 256
+    k = 1.0 / np.sqrt(H)
+    ps = [T(rng.uniform(-k, k, s), dev).requires_grad_() for s in ((4 * H, In), (4 * H, H), (4 * H,), (4 * H,))]
+    xs = [T(rng.uniform(-1, 1, (B, Tn, In)), dev).requires_grad_() for B in (1024, 512, 512)]
+    dys = [T(rng.uniform(-1, 1, (x.shape[0], Tn, H)), dev) for x in xs]
+
+    def run(x, dy):
+        y = ops.lstm_layer(x, *ps)
+        (gx,) = torch.autograd.grad(y, x, dy)
+        return y.detach(), gx
+
+    alone = [run(x, dy) for x, dy in zip(xs, dys)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    for _ in range(3):
+        got = []
+        for s, x, dy in zip(streams, xs, dys):
+            with torch.cuda.stream(s):
+                got.append(run(x, dy))
+    torch.cuda.synchronize()
+    ops.check_errors()
+    for (ya, ga), (yb, gb) in zip(alone, got):
+        assert torch.equal(ya, yb) and torch.equal(ga, gb)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_cfg4_long_context_two_layer_iteration(dev):
     """BASELINE.json configs[3] (window 1024, hidden 512, 2-layer) reduced to window 48 / batch 6: the D and
