@@ -304,7 +304,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   unsigned short* xH = wiL + 4 * US * LDX;                                // [2][MT*16][LDX] x_t tiles (t & 1), bf16 hi
   unsigned short* xL = xH + 2 * MT * 16 * LDX;
   float* bsum = reinterpret_cast<float*>(xL + 2 * MT * 16 * LDX);        // [4 gates][US] b_ih + b_hh of the member's units
-  float* xkeep = bsum + 4 * US;                                          // [256 lanes][8]: see XLDS
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, q = lane >> 4;
@@ -533,18 +532,30 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // Single-workgroup layers (NCL == 1) have no hand-off, but the matrix pipe idles during the gate math: there the x
   // part of a tile's next step is issued in front of the gate math of its current one, for every tile.
   constexpr bool XAHEAD = FUSE && (MT == 1 || NCL == 1);
-  // Hidden 256 has no registers left to carry that across the pull (256 per lane is the co-residency limit): there the
-  // two accumulators wait in LDS.
-  constexpr bool XLDS = XAHEAD && H >= 256 && DEAL;
   f32x4 accx[XAHEAD ? MT : 1][NR];
   if (XAHEAD) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xraw(0, mt, accx[mt]);
   }
-  if (XLDS) {
-    *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0][0];
-    *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[0][NR > 1 ? 1 : 0];
-  }   // the handshake's barriers above made the W_ih rows and x_0 visible
+  // (the handshake's barriers above made the W_ih rows and x_0 visible)
+  // STAGE: y and the stash of step tt from sbuf to HBM as whole 128-byte runs.  Piece (i, thread): item = 2 i + (wave >= 2)
+  // -- the four gates, c, y -- of row (tid >> 3) & 15, so every wave's store instruction has ONE destination (no per-lane
+  // branches), and the three LDS reads are all requested before the first store.  (Written as read -> store three times
+  // over with per-lane destinations, hipcc waited for each read in turn behind divergent branches: ~750 cycles at the
+  // top of every step.)
+  auto flush = [&](int tt) {
+    const int r = (tid >> 3) & 15, c4 = (tid & 7) * 4, hi = wave >> 1;
+    f32x4 v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + (2 * i + hi) * US + c4);
+    const long oy = (long)r * rowY + (long)tt * H + j * US + c4;
+    if (a.train) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) stg4<0>(rP, (long)r * rowP + (long)tt * 4 * H + (2 * i + hi) * H + j * US + c4, v[i]);
+    }
+    if (hi) stg4<0>(rY, oy, v[2]);
+    else if (a.train) stg4<0>(rC, oy, v[2]);
+  };
   STAMP_DECL;
 #ifdef TB_STAMPS
   stamp_acc[10] = same_l2 ? 1000 * T : 0;   // shows as 1000 per step when the cluster shares an L2
@@ -563,20 +574,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     for (int x = 0; x < MT; ++x) {
       const int mt = x;
       STAMP(0);
-      if (STAGE && t > 0) {
-        // y and the stash of step t-1, staged in sbuf before the barrier that ended that step
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg / 6, item = seg % 6;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + item * US + c4 * 4);
-          const long oy = (long)r * rowY + (long)(t - 1) * H + j * US + c4 * 4;
-          if (item == 5) stg4<0>(rY, oy, v);
-          else if (a.train) {
-            if (item == 4) stg4<0>(rC, oy, v);
-            else stg4<0>(rP, (long)r * rowP + (long)(t - 1) * 4 * H + item * H + j * US + c4 * 4, v);
-          }
-        }
-      }
+      if (STAGE && t > 0) flush(t - 1);   // y and the stash of step t-1, staged in sbuf before the barrier that ended that step
       // (A) every consumer has read h_mt(t-2) (it published h_mt(t-1) after that, and our pull of
       // h_mt(t-1) is complete): re-arm this wave's part of that slot, which is written next at step t+1
       if (NCL > 1 && t >= 2) {
@@ -622,10 +620,6 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (FUSE) {
         const int am = XAHEAD ? mt : 0;
         if (!XAHEAD) xraw(t, mt, accx[0]);
-        if (XLDS) {
-          accx[0][0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8);
-          accx[0][NR > 1 ? 1 : 0] = *reinterpret_cast<const f32x4*>(xkeep + tid * 8 + 4);
-        }
         xdeal(accx[am], acc);
         if (EMU2 && NXS == 1) {   // the 8-member layout deals one x k-step by gate: 0, 2 to the low k half, 1, 3 to the high one
           acc2[EMU2 ? 1 : 0] = acc[1]; acc2[EMU2 ? 3 : 0] = acc[3];
@@ -801,13 +795,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         *reinterpret_cast<u32x2*>(sb + 4 * US) = (u32x2){__float_as_uint(c[mt][0]), __float_as_uint(c[mt][UPW - 1])};
         *reinterpret_cast<u32x2*>(sb + 5 * US) = (u32x2){__float_as_uint(hn[0]), __float_as_uint(hn[UPW - 1])};
       }
-      if (XAHEAD && NCL > 1 && t + 1 < T) {
-        xraw(t + 1, 0, accx[0]);
-        if (XLDS) {   // a thread reads back what it wrote itself
-          *reinterpret_cast<f32x4*>(xkeep + tid * 8) = accx[0][0];
-          *reinterpret_cast<f32x4*>(xkeep + tid * 8 + 4) = accx[0][NR > 1 ? 1 : 0];
-        }
-      }
+      if (XAHEAD && NCL > 1 && t + 1 < T) xraw(t + 1, 0, accx[0]);
       STAMP(3);
       if (pull) {
         // (D) the other members' slices of h_pt(ps) from the ring into the LDS tile; wave w takes producers
@@ -926,19 +914,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     }
     if (NCL > 1 && *s_dead) break;
   }
-  if (STAGE && !*s_dead) {   // y and the stash of the last step (the loop ends with a barrier)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int pc = tid + 256 * i, seg = pc >> 3, c4 = pc & 7, r = seg / 6, item = seg % 6;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + item * US + c4 * 4);
-      const long oy = (long)r * rowY + (long)(T - 1) * H + j * US + c4 * 4;
-      if (item == 5) stg4<0>(rY, oy, v);
-      else if (a.train) {
-        if (item == 4) stg4<0>(rC, oy, v);
-        else stg4<0>(rP, (long)r * rowP + (long)(T - 1) * 4 * H + item * H + j * US + c4 * 4, v);
-      }
-    }
-  }
+  if (STAGE && !*s_dead) flush(T - 1);   // y and the stash of the last step (the loop ends with a barrier)
   STAMP_FLUSH(0, cl, j);
 }
 
@@ -1475,7 +1451,7 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
     if (mt == 1 && NCL > 1 && KS == 2 && US == 32)   // STAGE buffers of lstm_fwd_kernel: pbuf [2][16][4*US+8] (not fused), sbuf [16][6*US+8]
       b += ((size_t)(XK ? 0 : 2 * 16 * (4 * US + 8)) + (size_t)16 * (6 * US + 8)) * 4;
     if (XK)   // W_ih rows [4*US][XK+8] and x tiles [2][mt*16][XK+8], bf16 hi and lo each
-      b += ((size_t)4 * US + (size_t)2 * mt * 16) * (XK + 8) * 2 * 2 + (size_t)4 * US * 4 + (H >= 256 && mt == 1 ? 256 * 8 * 4 : 0);
+      b += ((size_t)4 * US + (size_t)2 * mt * 16) * (XK + 8) * 2 * 2 + (size_t)4 * US * 4;
     return b;
   };
   auto lds_b = [=](int mt) { return ((size_t)mt * 16 * (4 * US + 8) + (size_t)mt * 16 * (H + 4) + 4096) * 4 + 16; };
