@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   unsigned short* xL = xH + 2 * MT * 16 * LDX;
   float* bsum = reinterpret_cast<float*>(xL + 2 * MT * 16 * LDX);        // [4 gates][US] b_ih + b_hh of the member's units
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches and addresses
   const int col = lane & 15, q = lane >> 4;
   int cl, j;
   cluster_decode(NCL, cl, j);
@@ -544,7 +544,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // over with per-lane destinations, hipcc waited for each read in turn behind divergent branches: ~750 cycles at the
   // top of every step.)
   auto flush = [&](int tt) {
-    const int r = (tid >> 3) & 15, c4 = (tid & 7) * 4, hi = wave >> 1;
+    const int r = (tid >> 3) & 15, c4 = (tid & 7) * 4;
+    const int hi = __builtin_amdgcn_readfirstlane(wave >> 1);   // scalar: the destination select below is a branch, not a waterfall loop
     f32x4 v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const f32x4*>(sbuf + r * SROW + (2 * i + hi) * US + c4);
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   int* s_dead = reinterpret_cast<int*>(dbL + 4096);
   int* s_word = s_dead + 1;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches and addresses
   const int col = lane & 15, q = lane >> 4;
   int cl, j;
   cluster_decode(NCL, cl, j);
