@@ -715,7 +715,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
               const float lo = acc[g][u], hi = acc2[EMU2 ? g : 0][u];
               z[g][u] = u < 2 ? (lo + pre[mt][g][u]) + hi : (hi + pre[mt][g][u]) + lo;
             } else {
-              z[g][u] = acc[g][kp * UPW + u] + pre[mt][g][u];
+              // kp is wave-uniform: a scalar branch per k part with constant accumulator indices (indexed by kp directly,
+              // hipcc reads all 16 accumulators and picks with three selects per value)
+#pragma unroll
+              for (int kk = 0; kk < KS; ++kk)
+                if (kp == kk) z[g][u] = acc[g][kk * UPW + u] + pre[mt][g][u];
             }
           }
         if (KS > 1 && (FUSE || t > 0)) {
@@ -822,11 +826,21 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           }
         }
         STAMP(4);
+        // first round without per-lane predicates (which pieces a wave pulls is wave-uniform: straight-line loads, no
+        // exec juggling); the loop below only re-pulls what came back armed
+        if (MT == 1) {
+#pragma unroll
+          for (int n = 0; n < NLD; ++n) {
+            const int m = wave + (n / LPP) * NPW;
+            const int pc = (n % LPP) * 64 + lane, row = pc / (US / 4), c4 = pc % (US / 4);
+            if (m < NCL && m != j) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
+          }
+        }
         unsigned pend = 0;
 #pragma unroll
         for (int n = 0; n < NLD; ++n) {
           const int m = wave + (n / LPP) * NPW;
-          if (m < NCL && m != j && (MT == 1 || armed(buf[n]))) pend |= 1u << n;
+          if (m < NCL && m != j && armed(buf[n])) pend |= 1u << n;
         }
         unsigned it = 0;
         unsigned long long t0 = 0;
