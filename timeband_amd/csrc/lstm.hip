@@ -939,7 +939,7 @@ struct BwdArgs {
   const float* cst;    // [B][T][H]
   const float* dy;     // [B][T][H]
   const float* Whh;    // [4H][H]
-  float* X;            // [nclusters][3][NCL consumers][NCL producers][MT*16][US] exchange slabs (NCL > 1)
+  float* X;            // [nclusters][3][NCL consumers][NCL producers][US/16][MT*16][16] exchange slabs (NCL > 1)
   float* dbpart;       // [nclusters_total][4H] per-cluster bias-grad partials
   unsigned long long* hello;   // [nclusters][NCL] start-up handshake tags
   unsigned long long epoch;    // this launch's handshake epoch
@@ -985,6 +985,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int T = a.T;
   const long rowG = (long)T * 4 * H, rowY = (long)T * H;
   constexpr int XSLAB = NCL * NCL * MT * 16 * US;  // floats per slab
+  // Inside a (consumer, producer) block the 16-unit groups come first, then the rows: [US/16][MT*16][16].  A wave's
+  // partial-sum store -- 16 rows x 16 units -- is then one contiguous KB (8 full lines) instead of 64 bytes in each of
+  // 16 lines, and a reduce-scatter load instruction reads runs of 4 rows x 64 bytes.
+  auto xoff = [](int row, int u) { return (u >> 4) * (MT * 16 * 16) + row * 16 + (u & 15); };
   float* Xc = a.X + (size_t)cl * 3 * XSLAB;
   if (tid == 0) *s_dead = 0;
   int vrows = a.B - b0;
@@ -1173,7 +1177,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             const int n0 = (wave * NTW + nt) * 16 + q * 4;
             const int m = n0 / US;
             if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
-            else stx4(same_l2, rX, (long)par * XSLAB + ((long)(m * NCL + j) * MT * 16 + mt * 16 + col) * US + (n0 % US), acc[nt]);
+            else stx4(same_l2, rX, (long)par * XSLAB + (long)(m * NCL + j) * MT * 16 * US + xoff(mt * 16 + col, n0 % US), acc[nt]);
           }
         }
       }
@@ -1228,7 +1232,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < UI; ++r) s[r] = dhL[(mt * 16 + row) * LDH + uabs0 + r];
         if (NCL > 1) {
-          const long base = (long)par * XSLAB + ((long)(j * NCL) * MT * 16 + mt * 16 + row) * US + ul0;
+          const long base = (long)par * XSLAB + (long)(j * NCL) * MT * 16 * US + xoff(mt * 16 + row, ul0);
           f32x4 v[NCL];
 #pragma unroll
           for (int m = 0; m < NCL; ++m) v[m] = ldgn<UI, kSC1>(rX, base + (long)m * MT * 16 * US);
