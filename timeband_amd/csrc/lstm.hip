@@ -1135,23 +1135,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       __syncthreads();
       STAMP(2);
       if (NCL > 1 && *s_dead) break;   // a re-poll timed out (set before the barrier: uniform)
-      // (B0) Re-arm what the previous step consumed: this member's whole region of that step's slab -- its own
-      // never-written slot included -- as linear 16-byte pieces (whole lines; per-item 8-byte stores to 7 places
-      // took 7 store instructions of 16 partial lines each).  Every thread's loads of that region completed
-      // before the barrier above (their sums feed the gate math that precedes it), so any thread may re-arm any
-      // word.  The slab of step t+1 is written again at step t-2; its writers get there only after consuming this
-      // member's partial of step t-1, which is stored after the NEXT step's copy of the reduce-scatter wait --
-      // and that wait covers these stores.  So the re-arm always lands before the next write.
-      if (NCL > 1 && t < T - 1) {
-        const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
-        constexpr int PER = NCL * MT * 16 * US / 4;   // 16-byte pieces of this member's region
-        const long rb = (long)((t + 1) % 3) * XSLAB + (long)j * NCL * MT * 16 * US;
-#pragma unroll
-        for (int i = 0; i < (PER + 255) / 256; ++i) {
-          const int pc = tid + 256 * i;
-          if (PER % 256 == 0 || pc < PER) stx4(same_l2, rX, rb + (long)pc * 4, arm);
-        }
-      }
       // (B) partial dh_{t-1}^T = W_hh[rows of this member]^T . dgates_t^T
       if (mactive) {
 #pragma unroll
@@ -1179,6 +1162,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
             else stx4(same_l2, rX, (long)par * XSLAB + (long)(m * NCL + j) * MT * 16 * US + xoff(mt * 16 + col, n0 % US), acc[nt]);
           }
+        }
+      }
+      // (B0) [issued behind the MFMA block and the partial-sum stores: nothing waits for it before the end of the step]
+      // Re-arm what the previous step consumed: this member's whole region of that step's slab -- its own
+      // never-written slot included -- as linear 16-byte pieces (whole lines; per-item 8-byte stores to 7 places
+      // took 7 store instructions of 16 partial lines each).  Every thread's loads of that region completed
+      // before the barrier above (their sums feed the gate math that precedes it), so any thread may re-arm any
+      // word.  The slab of step t+1 is written again at step t-2; its writers get there only after consuming this
+      // member's partial of step t-1, which is stored after the NEXT step's copy of the reduce-scatter wait --
+      // and that wait covers these stores.  So the re-arm always lands before the next write.
+      if (NCL > 1 && t < T - 1) {
+        const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
+        constexpr int PER = NCL * MT * 16 * US / 4;   // 16-byte pieces of this member's region
+        const long rb = (long)((t + 1) % 3) * XSLAB + (long)j * NCL * MT * 16 * US;
+#pragma unroll
+        for (int i = 0; i < (PER + 255) / 256; ++i) {
+          const int pc = tid + 256 * i;
+          if (PER % 256 == 0 || pc < PER) stx4(same_l2, rX, rb + (long)pc * 4, arm);
         }
       }
       STAMP(3);
