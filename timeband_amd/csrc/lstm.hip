@@ -374,6 +374,11 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         v1 = *reinterpret_cast<const f32x4*>(wp + 4);
       }
       tb_split8(v0, v1, whi[g][s], wlo[g][s]);
+      // 4-member layout: 256 registers of fragments do not fit the 256 architectural VGPRs beside the working set.  Left
+      // to the allocator, half of them are spilled to accumulation registers and copied back in front of every MFMA
+      // (4 v_accvgpr_read per use, all through one temporary); pinned there as values of the AGPR class, the MFMAs
+      // read them in place.
+      if (EMU2) asm volatile("" : "+a"(wlo[g][s]));
     }
   // W_ih fragments: in LDS for the clustered variants (no registers to spare: two of their launches must fit a CU),
   // in registers like W_hh for single-workgroup layers (re-reading them every step would put 40-80 KB per step
@@ -1028,6 +1033,9 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         }
       }
       tb_split8(v0, v1, wbh[nt][s], wbl[nt][s]);
+      // 4-member layout (256 registers of fragments): the lo halves live in accumulation registers, where the MFMAs read
+      // them in place (left to the allocator they are spilled there and copied back in front of every use)
+      if (H == 256 && US == 64) asm volatile("" : "+a"(wbl[nt][s]));
     }
   // elementwise items: e = tid + 256*n -> unit group qd (constant per thread) of UI units, row, mt
   // (f32x4 containers, the first UI elements in use)
