@@ -204,15 +204,17 @@ class TIMEBANDTrainer:
             with torch.cuda.stream(s2):          # G-phase generator forward, under the D-phase backward
                 fake_y2 = netG(true_x)
             fake_y2.record_stream(main)
+        dphase = None
         if training:
             self.optimD.begin_reduce()           # D's gradients are complete after this backward pass
             errD.backward()
             if share:
                 dfake_dphase = fake_y.grad
-            elif ov4:        # the generator's share of errD.backward(), under the G-phase discriminator pass
-                s1.wait_stream(main)
-                with torch.cuda.stream(s1):
-                    fake_g.backward(fake_y.grad)
+            elif ov4:        # the generator's share of errD.backward(), under the G-phase forward and discriminator pass
+                # Enqueued BEHIND the G-phase generator forward (below): the host needs a few hundred microseconds to queue a
+                # whole generator backward, and the main stream -- the critical chain -- would sit idle meanwhile.
+                dphase = (fake_g, fake_y.grad, torch.cuda.Event())
+                dphase[2].record(main)
         # generator phase.  errG.backward() of the reference also accumulates into D's parameter
         # gradients (trainer.py:183-186); the next zero_grad (:146 / :160) clears them unread, so D's
         # weight gradients are not computed here -- only the path through D back to fake_y.
@@ -228,6 +230,11 @@ class TIMEBANDTrainer:
                     fake_y = fake_y2
                 else:
                     fake_y = netG(true_x)
+                if dphase is not None:
+                    s1.wait_event(dphase[2])
+                    with torch.cuda.stream(s1):
+                        dphase[0].backward(dphase[1])
+                    dphase = None
                 # data parallel: the all-reduce of the gradient-penalty norm's sums starts here and runs under
                 # the discriminator pass below
                 presum = self.losses.recon_presum(true_y, fake_y) if training else None
