@@ -63,6 +63,12 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
                 float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
                 int* err, void* stream);
+/* tb_lstm_bwd with dx computed for the batch rows [dx_row_begin, B) only (rows before are left untouched): the
+ * discriminator's real + fake pass reads the input gradient of the fake half alone (trainer.py:174-180). */
+int tb_lstm_bwd_rows(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
+                int* err, void* stream, int dx_row_begin);
 
 /* The weight-gradient products of tb_lstm_bwd on their own (autograd of source/utils/lstm_layer.py:44-46,83):
  * dw_ih (4H,in) = dG^T.x, dw_hh (4H,H) = dG^T.h_prev with `dgates` = the gates buffer AFTER tb_lstm_bwd.  Call

@@ -412,3 +412,31 @@ def test_shared_generator_pass_matches_two_passes(dev):
         nbad += int((d > 0.05 * lr).sum())
         ntot += d.numel()
     assert nbad / ntot < 2e-3, (nbad, ntot)
+
+
+def test_pair_pass_skips_only_the_real_half_input_gradient(dev):
+    """LSTMDiscriminator.pair computes the input gradient of the fake half alone (tb_lstm_bwd_rows): it must equal,
+    bit for bit, the fake half of the full input gradient, and the parameter gradients must not change."""
+    V, E, To, Tf, H, L = 8, 12, 24, 24, 128, 2
+    netD, _ = make_nets(V, E, To, Tf, H, L, dev)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    real = (torch.rand(40, Tf, V, generator=g) * 2 - 1).to(dev)
+    fake = (torch.rand(40, Tf, V, generator=g) * 2 - 1).to(dev)
+    w = (torch.rand(80, Tf, 1, generator=g)).to(dev)
+
+    def run(pair):
+        netD.zero_grad(set_to_none=True)
+        f = fake.clone().requires_grad_()
+        if pair:
+            Dy, DGx = netD.pair(real, f)
+            out = torch.cat([Dy, DGx], 0)
+        else:
+            out = netD(torch.cat([real, f], 0))
+        (out * w).sum().backward()
+        return f.grad.clone(), [p.grad.clone() for p in netD.parameters()]
+
+    ga, pa = run(True)
+    gb, pb = run(False)
+    assert torch.equal(ga, gb)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

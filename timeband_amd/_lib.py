@@ -38,6 +38,7 @@ SIGNATURES = {
     "tb_lstm_static_scratch_bytes": (Z, []),
     "tb_lstm_fwd_static": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "tb_lstm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_bwd_rows": (I, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P, I]),
     "tb_linear_act_fwd": (I, [P, P, P, P, I, I, I, I, P]),
     "tb_linear_workspace_bytes": (Z, [I, I, I]),
     "tb_linear_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, Z, P]),

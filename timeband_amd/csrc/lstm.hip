@@ -1741,10 +1741,35 @@ int tb_lstm_fwd_static(const float* x, const float* w_ih, const float* w_hh, con
                        stream, false);
 }
 
+static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                         float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                         float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, int* err,
+                         void* stream, int dx_row_begin);
+
 int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
                 float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, int* err,
                 void* stream) {
+  return lstm_bwd_impl(dy, x, w_ih, w_hh, y, gates, cstash, dx, dw_ih, dw_hh, db_ih, db_hh, B, T, in_dim, H, accumulate, ws,
+                       ws_bytes, err, stream, 0);
+}
+
+// tb_lstm_bwd with dx computed for the batch rows [dx_row_begin, B) only; the rows before are left untouched.
+int tb_lstm_bwd_rows(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                     float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                     float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, int* err,
+                     void* stream, int dx_row_begin) {
+  if (dx_row_begin < 0 || dx_row_begin > B) return tb_set_error(TB_ERR_ARG, "lstm_bwd_rows: dx_row_begin out of range");
+  return lstm_bwd_impl(dy, x, w_ih, w_hh, y, gates, cstash, dx, dw_ih, dw_hh, db_ih, db_hh, B, T, in_dim, H, accumulate, ws,
+                       ws_bytes, err, stream, dx_row_begin);
+}
+
+}  // extern "C"
+
+static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
+                         float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                         float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, int* err,
+                         void* stream, int dx_row_begin) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
   if (!dy || !x || !w_ih || !w_hh || !y || !gates || !cstash || !ws || !err)
@@ -1781,9 +1806,10 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   }
   tb_prof_end(TB_K_LSTM_BWD, s);
   const int M = B * T;
-  if (dx) {   // dx = dG . W_ih            [M,4H].[4H,in]   (first: the layer below waits for it)
-    rc = tb_gemm_launch(gates, 4L * H, 0, w_ih, in_dim, 1, dx, in_dim, nullptr, M, in_dim, 4 * H, 0, 0, 1,
-                        c.gemm_ws, c.gemm_ws_bytes, s, 0);
+  if (dx && dx_row_begin < B) {   // dx = dG . W_ih            [M,4H].[4H,in]   (first: the layer below waits for it)
+    const long r0 = (long)dx_row_begin * T;   // only the rows whose input gradient somebody reads
+    rc = tb_gemm_launch(gates + r0 * 4 * H, 4L * H, 0, w_ih, in_dim, 1, dx + r0 * in_dim, in_dim, nullptr, (int)(M - r0), in_dim,
+                        4 * H, 0, 0, 1, c.gemm_ws, c.gemm_ws_bytes, s, 0);
     if (rc) return rc;
   }
   WFinishArgs f;
@@ -1803,6 +1829,8 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
   f.db_ih = db_ih; f.db_hh = db_hh; f.db_acc = accumulate;
   return launch_wgrad_finish(f, s);
 }
+
+extern "C" {
 
 size_t tb_lstm_wgrad_workspace_bytes(int in_dim, int H) {
   (void)in_dim; (void)H;

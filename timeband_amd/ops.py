@@ -166,9 +166,10 @@ def grads_enqueued(slots, params):
 # ----------------------------------------------------------------------------------------------
 class _LSTMLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train, dx_from=0):
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
+        ctx.dx_from = int(dx_from)
         x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
         B, T, In = x.shape
         H = w_hh.shape[1]
@@ -224,9 +225,12 @@ class _LSTMLayerFn(torch.autograd.Function):
         excl = H > 64 and bool(lib.tb_lstm_exclusive(B, In, H, 1))
         if H > 64:
             rt.clustered_begin(excl)
-        _lib.call("tb_lstm_bwd", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
+        # dx_from: the input gradient of the batch rows before it is never read (the real half of the discriminator's
+        # real + fake pass) and is not computed; those rows of dx stay as allocated
+        _lib.call("tb_lstm_bwd_rows", _ptr(dy), _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(y), _ptr(gates), _ptr(cst),
                   _ptr(dx), _ptr(None if side else dw_ih), _ptr(None if side else dw_hh), _ptr(db_ih), _ptr(db_hh),
-                  B, T, In, H, 1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+                  B, T, In, H, 1 if slots is not None else 0, _ptr(ws), ws.numel(), _ptr(rt.err), _stream(),
+                  min(max(ctx.dx_from, 0), B))
         if H > 64:
             rt.clustered_end(excl)
         if side:
@@ -241,25 +245,28 @@ class _LSTMLayerFn(torch.autograd.Function):
                     t.record_stream(wg)
                 rt._wg_dirty = True
                 grads_enqueued(slots, ctx.params)      # an armed reducer records its event on THIS stream
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None
         if slots is not None:
             grads_enqueued(slots, ctx.params)
-            return dx, None, None, None, None, None
-        return dx, dw_ih, dw_hh, db_ih, db_hh, None
+            return dx, None, None, None, None, None, None
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None
 
 
-def lstm_layer(x, w_ih, w_hh, b_ih, b_hh):
-    """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H)."""
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0):
+    """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H).  dx_from: the caller promises that nobody reads
+    the input gradient of the batch rows [0, dx_from) -- it is then not computed (those rows of x.grad are garbage)."""
     # grad mode is off inside Function.forward, so the stash decision is taken here
     train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh)))
-    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train)
+    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from)
 
 
-def lstm_stack(x, lstm_module):
-    """Run x through the layers of a torch.nn.LSTM parameter container with the HIP kernels."""
+def lstm_stack(x, lstm_module, dx_from=0):
+    """Run x through the layers of a torch.nn.LSTM parameter container with the HIP kernels (dx_from: see lstm_layer;
+    it applies to the first layer, whose input is x)."""
     for l in range(lstm_module.num_layers):
         x = lstm_layer(x, getattr(lstm_module, f"weight_ih_l{l}"), getattr(lstm_module, f"weight_hh_l{l}"),
-                       getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"))
+                       getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"),
+                       dx_from if l == 0 else 0)
     return x
 
 

@@ -73,9 +73,9 @@ class LSTMDiscriminator(nn.Module):
         """Gen-B argument order (reference source/models.py:91)."""
         return cls(in_dim, hid_dim, n_layers, device)
 
-    def forward(self, input):
+    def forward(self, input, dx_from=0):
         B, T = input.size(0), input.size(1)
-        r = ops.lstm_stack(input, self.lstm)
+        r = ops.lstm_stack(input, self.lstm, dx_from)
         lin = self.linear[0]
         out = ops.linear_act(r.view(B * T, self.hidden_dim), lin.weight, lin.bias, ops.ACT_SIGMOID)
         return out.view(B, T, 1)
@@ -87,6 +87,7 @@ class LSTMDiscriminator(nn.Module):
         of B (and the weight-gradient GEMMs run once over both halves)."""
         if real.shape != fake.shape:
             return self(real), self(fake)
-        out = self(torch.cat([real, fake], 0))
+        # the real half is data: nobody reads its input gradient, so the first layer does not compute it
+        out = self(torch.cat([real, fake], 0), dx_from=0 if real.requires_grad else real.size(0))
         Dy, DGx = out.view(2, real.size(0), real.size(1), 1).unbind(0)
         return Dy, DGx
