@@ -125,13 +125,14 @@ int tb_head_bwd(const float* dy, const float* out, const float* x, const float* 
  *                 mode 1 critic dis_loss (loss.py:107-112) out=[total,real,fake,gp];
  *                 mode 2 gen_loss (loss.py:93-104) out=[total,adv,l1,l2,gp].
  *   nD_*, nP, batch are GLOBAL element counts / batch size.  `running` (nullable float[8])
- *   accumulates the logging sums of loss.py:99-102,117-118.
+ *   accumulates the logging sums of loss.py:99-102,117-118; `total` (nullable float[1]) receives
+ *   out[0] in separate storage (the differentiable scalar the host hands to autograd).
  * grads: `upstream` is a device float (dL/dloss, nullable = 1). */
 size_t tb_loss_workspace_bytes(void);
 int tb_loss_sums(const float* Dy, long nDy, const float* DGx, long nDGx, const float* tru, const float* pred,
                  long nP, double* sums, void* ws, size_t ws_bytes, void* stream);
 int tb_loss_finish(const double* sums, int mode, double nD_real, double nD_fake, double nP, double batch,
-                   float l1_w, float l2_w, float gp_w, float* out, float* running, void* stream);
+                   float l1_w, float l2_w, float gp_w, float* out, float* running, float* total, void* stream);
 int tb_gan_loss_grad(const float* p, long n_local, double n_global, int target_is_real, int wgan,
                      const float* upstream, float* dp, void* stream);
 int tb_recon_loss_grad(const float* tru, const float* pred, long n_local, double n_global, double batch,

@@ -51,7 +51,7 @@ SIGNATURES = {
     "tb_head_bwd": (I, [P, P, P, P, P, P, P, L, I, I, I, P, Z, P]),
     "tb_loss_workspace_bytes": (Z, []),
     "tb_loss_sums": (I, [P, L, P, L, P, P, L, P, P, Z, P]),
-    "tb_loss_finish": (I, [P, I, D, D, D, D, F, F, F, P, P, P]),
+    "tb_loss_finish": (I, [P, I, D, D, D, D, F, F, F, P, P, P, P]),
     "tb_gan_loss_grad": (I, [P, L, D, I, I, P, P, P]),
     "tb_recon_loss_grad": (I, [P, P, L, D, D, P, F, F, F, P, P, I, P]),
     "tb_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),

@@ -77,7 +77,7 @@ __global__ void loss_final_kernel(const double* __restrict__ part, int nblocks, 
 // running (nullable, float[8]): D: [0]+=real [1]+=fake ; G: [2]+=adv [3]+=l1 [4]+=l2 [5]+=gp
 __global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, double nD_real, double nD_fake,
                                    double nP, double batch, float l1_w, float l2_w, float gp_w, float* out,
-                                   float* running) {
+                                   float* running, float* total) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (mode == 0) {
     const float real = (float)(sums[0] / nD_real), fake = (float)(sums[1] / nD_fake);
@@ -97,6 +97,7 @@ __global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, do
     out[0] = adv + l1 + l2 + gp; out[1] = adv; out[2] = l1; out[3] = l2; out[4] = gp;
     if (running) { running[2] += adv; running[3] += l1; running[4] += l2; running[5] += gp; }
   }
+  if (total) total[0] = out[0];
 }
 
 // d(loss)/dD for the adversarial terms.  lsgan: up * 2 (p - label) / n ; wgan: up * sign / n
@@ -241,11 +242,11 @@ int tb_loss_sums(const float* Dy, long nDy, const float* DGx, long nDGx, const f
 }
 
 int tb_loss_finish(const double* sums, int mode, double nD_real, double nD_fake, double nP, double batch,
-                   float l1_w, float l2_w, float gp_w, float* out, float* running, void* stream) {
+                   float l1_w, float l2_w, float gp_w, float* out, float* running, float* total, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!sums || !out) return tb_set_error(TB_ERR_ARG, "loss_finish: null pointer");
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, sums, mode, nD_real, nD_fake, nP, batch, l1_w,
-                     l2_w, gp_w, out, running);
+                     l2_w, gp_w, out, running, total);
   TB_LAUNCH_CHECK("loss_finish_kernel");
   return TB_OK;
 }

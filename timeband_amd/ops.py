@@ -444,17 +444,19 @@ class _DisLossFn(torch.autograd.Function):
         nP = dp.count_scale(pred.numel()) if critic else 1.0
         batch = dp.count_scale(tru.shape[0]) if critic else 1.0
         nDy, nDGx = dp.count_scale(Dy.numel()), dp.count_scale(DGx.numel())
-        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, nDy, nDGx,
-                  nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), _ptr(None if critic else running), _stream())
+        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs
+        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, nDy, nDGx,  # must not alias each other
+                  nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), _ptr(None if critic else running), _ptr(total), _stream())
         ctx.critic, ctx.gp_w, ctx.counts = critic, gp_w, (nDy, nDGx, nP, batch)
         ctx.save_for_backward(Dy, DGx, tru if critic else None, pred if critic else None, sums)
-        total = torch.empty((), dtype=torch.float32, device=out.device)
-        total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)     # no zero-fill launch for `out`'s unused gradient
         return total, out
 
     @staticmethod
     def backward(ctx, gtotal, _gout):
+        if gtotal is None:
+            return (None,) * 7
         Dy, DGx, tru, pred, sums = ctx.saved_tensors
         nDy, nDGx, nP, batch = ctx.counts
         up = _f32c(gtotal)
@@ -490,18 +492,20 @@ class _GenLossFn(torch.autograd.Function):
                 dp.all_reduce(sums[4:6])
         out = torch.empty(8, dtype=torch.float32, device=pred.device)
         nDGx, nP, batch = dp.count_scale(DGx.numel()), dp.count_scale(pred.numel()), dp.count_scale(tru.shape[0])
+        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs
         _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, nDGx, nP, batch, float(l1_w), float(l2_w), float(gp_w),
-                  _ptr(out), _ptr(running), _stream())
+                  _ptr(out), _ptr(running), _ptr(total), _stream())             # must not alias each other
         ctx.w = (l1_w, l2_w, gp_w)
         ctx.counts = (nDGx, nP, batch)
         ctx.save_for_backward(tru, pred, DGx, sums)
-        total = torch.empty((), dtype=torch.float32, device=out.device)
-        total.copy_(out[0])      # separate storage: autograd outputs must not alias each other
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)     # no zero-fill launch for `out`'s unused gradient
         return total, out
 
     @staticmethod
     def backward(ctx, gtotal, _gout):
+        if gtotal is None:
+            return (None,) * 8
         tru, pred, DGx, sums = ctx.saved_tensors
         l1_w, l2_w, gp_w = ctx.w
         nDGx, nP, batch = ctx.counts

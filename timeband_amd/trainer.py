@@ -58,6 +58,14 @@ class TIMEBANDTrainer:
         # stream (ops.Runtime.wgrad_stream); the optimizers join it before they read the gradients
         self.wgrad_overlap = os.environ.get("TB_WGRAD_OVERLAP", "0") == "1"
         self._side = None
+        self._ones = {}
+
+    def _one(self, loss):
+        """d(loss)/d(loss) = 1 from a cached device scalar: backward() without autograd's ones-fill launch."""
+        one = self._ones.get(loss.device)
+        if one is None:
+            one = self._ones[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return one
 
     def set_config(self, config: dict = None) -> None:
         self.__dict__ = {**config, **self.__dict__}
@@ -121,7 +129,7 @@ class TIMEBANDTrainer:
         Dy, DGx = netD.pair(true_y, fake_y)
         errD = self.losses.dis_loss(true_y, fake_y, Dy, DGx, critic=True)
         self._critic_opt.begin_reduce()
-        errD.backward()
+        errD.backward(self._one(errD))
         self._critic_opt.all_reduce_grads()
         self._critic_opt.step()
 
@@ -207,7 +215,7 @@ class TIMEBANDTrainer:
         dphase = None
         if training:
             self.optimD.begin_reduce()           # D's gradients are complete after this backward pass
-            errD.backward()
+            errD.backward(self._one(errD))
             if share:
                 dfake_dphase = fake_y.grad
             elif ov4:        # the generator's share of errD.backward(), under the G-phase forward and discriminator pass
@@ -250,7 +258,7 @@ class TIMEBANDTrainer:
             if training:
                 if not (share or ov4):
                     self.optimG.begin_reduce()   # errG.backward() runs through D into G: G's last backward pass
-                errG.backward()
+                errG.backward(self._one(errG))
                 if share:
                     self.optimG.begin_reduce()
                     fake_g.backward(dfake_dphase + fake_y.grad)
