@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtimeband_hip.so")
+LIB_PATH = os.environ.get("TB_LIB_PATH") or os.path.join(_HERE, "libtimeband_hip.so")   # TB_LIB_PATH: A/B builds (tools)
 
 _lib = None
 

@@ -810,26 +810,12 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (pull) {
         // (D) the other members' slices of h_pt(ps) from the ring into the LDS tile; wave w takes producers
         // w, w+4, ...  The ring is sentinel-armed and every slot word is written once per turn, so the data
-        // is its own ready flag: poll the last piece of each unit group of each of my producers (a piece is
-        // complete when none of its 4 words is armed: its parts come from different waves), then pull, then
-        // re-pull whatever is still armed.  Only the ring store above precedes these loads in this wave's
-        // memory queue: y and the stash are stored after the pull.
-        if (MT == 1 && lane < NPP * NUG) {
-          const int m = wave + (lane / NUG) * NPW;
-          if (m < NCL && m != j) {
-            const int voff = (int)((sbase + (long)15 * H + m * US + (lane % NUG) * 16 + 12) * 4);
-            const unsigned long long t0 = wall_clock64();
-            unsigned it = 0;
-            while (armed(__builtin_amdgcn_raw_buffer_load_b128(rR, voff, 0, kSC1))) {
-              __builtin_amdgcn_s_sleep(1);
-              if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
-                atomicExch(a.err, 1);
-                *s_dead = 1;
-                break;
-              }
-            }
-          }
-        }
+        // is its own ready flag: pull, then re-pull whatever is still armed (a piece is complete when none of
+        // its 4 words is armed: its parts come from different waves).  No separate poll of one piece in front of
+        // the pull: the x part above (or the other tiles' phases) covers most of the hand-off, so the first pull
+        // usually finds the data and a poll only added an L2 round trip (2.62 -> 2.48 us/step at hidden 256).
+        // Only the ring store above precedes these loads in this wave's memory queue: y and the stash are
+        // stored after the pull.
         STAMP(4);
         // first round without per-lane predicates (which pieces a wave pulls is wave-uniform: straight-line loads, no
         // exec juggling); the loop below only re-pulls what came back armed
