@@ -1028,11 +1028,28 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const int qd = tid % QPR;
   const int ul0 = qd * UI, uabs0 = j * US + ul0;
   f32x4 dc[NQ], dhrec[NQ], dbacc[4];
-  // stash of the current step (prefetched one step ahead): i, f, g, o, c_t, c_{t-1}, dy
-  f32x4 cur[NQ][7];
+  // Per item, the factors of a step's gate gradients that do not depend on dh_t -- computed a step AHEAD, in the shadow of
+  // the previous step's hand-off, so that only seven multiply-adds per unit sit between the reduce-scatter and the LDS tile:
+  //   [0] o (1 - tanh^2 c_t)   [1] tanh(c_t) o (1 - o)   [2] g i (1 - i)   [3] i (1 - g^2)   [4] c_{t-1} f (1 - f)   [5] f
+  // then dy_t, and c_{t-1} (which is the next step's c_t).  (f32x4 containers, the first UI elements in use.)
+  f32x4 fac[NQ][6], dyv[NQ], cprev[NQ];
+  auto mkfac = [&](f32x4 (&o)[6], const f32x4& gi, const f32x4& gf, const f32x4& gg, const f32x4& go, const f32x4& ct, const f32x4& cp) {
+#pragma unroll
+    for (int r = 0; r < UI; ++r) {
+      const float tc = ftanh(ct[r]);
+      // explicit fma: left to -ffp-contract the compiler may pick differently per instantiation, and the layouts must agree bit for bit
+      o[0][r] = go[r] * __builtin_fmaf(-tc, tc, 1.f);
+      o[1][r] = tc * go[r] * (1.f - go[r]);
+      o[2][r] = gg[r] * gi[r] * (1.f - gi[r]);
+      o[3][r] = gi[r] * __builtin_fmaf(-gg[r], gg[r], 1.f);
+      o[4][r] = cp[r] * gf[r] * (1.f - gf[r]);
+      o[5][r] = gf[r];
+    }
+  };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < 4; ++g) dbacc[g] = zero4;
+  f32x4 raw0[NQ][6];   // the last step's stash: i, f, g, o, c_{T-1}, c_{T-2}
 #pragma unroll
   for (int n = 0; n < NQ; ++n) {
     dc[n] = zero4; dhrec[n] = zero4;
@@ -1041,10 +1058,10 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     const long rr = mt * 16 + row;
     const bool ok = e < NE;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) cur[n][g] = ok ? ldgn<UI, 0>(rG, rr * rowG + (long)(T - 1) * 4 * H + g * H + uabs0) : zero4;
-    cur[n][4] = ok ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
-    cur[n][5] = (ok && T > 1) ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
-    cur[n][6] = ok ? ldgn<UI, 0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
+    for (int g = 0; g < 4; ++g) raw0[n][g] = ok ? ldgn<UI, 0>(rG, rr * rowG + (long)(T - 1) * 4 * H + g * H + uabs0) : zero4;
+    raw0[n][4] = ok ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
+    raw0[n][5] = (ok && T > 1) ? ldgn<UI, 0>(rC, rr * rowY + (long)(T - 2) * H + uabs0) : zero4;
+    dyv[n] = ok ? ldgn<UI, 0>(rD, rr * rowY + (long)(T - 1) * H + uabs0) : zero4;
   }
   bool same_l2 = false;
   if (NCL > 1) {
@@ -1055,7 +1072,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   } else {
     __syncthreads();
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // the first step's stash is in registers before the loop (loop-carried state)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // the first step's stash is in registers before the loop
+#pragma unroll
+  for (int n = 0; n < NQ; ++n) {
+    mkfac(fac[n], raw0[n][0], raw0[n][1], raw0[n][2], raw0[n][3], raw0[n][4], raw0[n][5]);
+    cprev[n] = raw0[n][5];
+  }
 
   STAMP_DECL;
   for (int t = T - 1; t >= 0; --t) {
@@ -1071,16 +1093,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       for (int g = 0; g < 4; ++g) dgv[n][g] = zero4;
 #pragma unroll
       for (int r = 0; r < UI; ++r) {
-        const float ig = cur[n][0][r], fg = cur[n][1][r], gg = cur[n][2][r], og = cur[n][3][r];
-        const float dh = cur[n][6][r] + dhrec[n][r];
-        const float tc = ftanh(cur[n][4][r]);
-        const float dcn = dc[n][r] + dh * og * (1.f - tc * tc);
-        const float dob = dh * tc * og * (1.f - og);
-        const float di = dcn * gg * ig * (1.f - ig);
-        const float dg = dcn * ig * (1.f - gg * gg);
-        const float df = dcn * cur[n][5][r] * fg * (1.f - fg);
-        dc[n][r] = dcn * fg;
-        dgv[n][0][r] = di; dgv[n][1][r] = df; dgv[n][2][r] = dg; dgv[n][3][r] = dob;
+        const float dh = dyv[n][r] + dhrec[n][r];
+        const float dcn = __builtin_fmaf(dh, fac[n][0][r], dc[n][r]);
+        dgv[n][0][r] = dcn * fac[n][2][r];
+        dgv[n][1][r] = dcn * fac[n][4][r];
+        dgv[n][2][r] = dcn * fac[n][3][r];
+        dgv[n][3][r] = dh * fac[n][1][r];
+        dc[n][r] = dcn * fac[n][5][r];
       }
       if (e < NE) {
 #pragma unroll
@@ -1192,32 +1211,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     }
     STAMP(5);
     if (last) break;
-    if (NCL > 1) {
-      // Data-as-flag: the slabs are armed with the sentinel (all-ones) before the launch, a slot that
-      // holds a value is ready, and the consumer re-arms what it has consumed.  One wave polls one
-      // piece per producer (the last one it stores), then every thread pulls its pieces and re-polls
-      // only those still armed.
-      if (wave == 0 && lane < NCL && lane != j) {
-        const int voff = (int)(((long)par * XSLAB + ((long)(j * NCL + lane) * MT * 16 + MT * 16 - 1) * US + US - 4) * 4);
-        const unsigned long long t0 = wall_clock64();
-        unsigned it = 0;
-        while (true) {
-          if (!armed(__builtin_amdgcn_raw_buffer_load_b128(rX, voff, 0, kSC1))) break;
-          __builtin_amdgcn_s_sleep(1);
-          if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
-            atomicExch(a.err, 1);
-            *s_dead = 1;
-            break;
-          }
-        }
-      }
-      STAMP(6);
-      __syncthreads();
-      STAMP(7);
-      if (*s_dead) break;
+    // the next step's dh-independent factors, while the partial sums travel (c_{t-1} is held; its stash and dy were
+    // requested a whole MFMA block ago)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+      mkfac(fac[n], nx[n][0], nx[n][1], nx[n][2], nx[n][3], cprev[n], nx[n][4]);
+      cprev[n] = nx[n][4];
+      dyv[n] = nx[n][5];
     }
+    STAMP(6);
+    STAMP(7);
     // (C) reduce-scatter: dh_{t-1} for this member's units = own partial + the other members' partials
-    // (every slot is loaded, the never-written own one included: one predicate-free burst)
+    // (every slot is loaded, the never-written own one included: one predicate-free burst).
+    // Data-as-flag: the slabs are armed with the sentinel (all-ones) before the launch, a slot that holds a value is
+    // ready, and the consumer re-arms what it has consumed.  Every thread pulls its pieces and pulls again what came
+    // back armed -- no poll of one piece per producer and no barrier in front: with the factor math above in the
+    // shadow of the hand-off the first pull usually finds the data (2.58 -> 2.47 us/step at hidden 256), and the own
+    // partial in dhL was made visible by the barrier behind the MFMA block.  A timeout is seen by the whole
+    // workgroup behind the next step's first barrier.
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
       const int e = tid + 256 * n;
@@ -1238,7 +1249,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
               if (m != j && armedn<UI>(v[m])) pend |= 1u << m;
             unsigned it = 0;
             unsigned long long t0 = 0;
-            while (pend) {   // rare: a piece behind the polled one
+            while (pend) {
               asm volatile("" ::: "memory");
 #pragma unroll
               for (int m = 0; m < NCL; ++m)
@@ -1263,22 +1274,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int r = 0; r < UI; ++r) s[r] += other ? v[m][r] : 0.f;
           }
-          // (what was consumed is re-armed at the top of the next step, as whole lines: see (B0) there)
-          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the compiler then KNOWS every earlier load has landed --
-                                                // the prefetched stash of the next step included -- and does not
-                                                // start the next step's gate math with a wait of its own
+          // (what was consumed is re-armed in the next step, as whole lines: see (B0) there)
         }
         dhrec[n] = s;
       }
     }
     STAMP(8);
     if (NCL == 1) __syncthreads();   // dhL free for the next step (NCL > 1: the waits' barriers order it)
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-      cur[n][4] = cur[n][5];
-      cur[n][0] = nx[n][0]; cur[n][1] = nx[n][1]; cur[n][2] = nx[n][2]; cur[n][3] = nx[n][3];
-      cur[n][5] = nx[n][4]; cur[n][6] = nx[n][5];
-    }
   }
   STAMP_FLUSH(1, cl, j);
   // bias grads of this cluster: reduce the threads that share a unit group, one partial row per cluster
