@@ -37,6 +37,7 @@
 // All spins are bounded (2 s) and report through the caller's err word.  NCL == 1 (H <= 64) needs
 // no global exchange at all.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
@@ -1167,14 +1168,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbh[nt][s], bh, acc[nt], 0, 0, 0);
           }
-          // lane: batch row `col`, output units n0 .. n0+3
+          // lane: batch row `col`, output units n0 .. n0+3.  ONE branch on the store kind around the whole burst (a
+          // branch per store: ~20 scalar branches per step in this block alone)
+          auto put = [&](auto sc) {
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            const int n0 = (wave * NTW + nt) * 16 + q * 4;
-            const int m = n0 / US;
-            if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
-            else stx4(same_l2, rX, (long)par * XSLAB + (long)(m * NCL + j) * MT * 16 * US + xoff(mt * 16 + col, n0 % US), acc[nt]);
-          }
+            for (int nt = 0; nt < NTW; ++nt) {
+              const int n0 = (wave * NTW + nt) * 16 + q * 4;
+              const int m = n0 / US;
+              if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
+              else stg4<decltype(sc)::value>(rX, (long)par * XSLAB + (long)(m * NCL + j) * MT * 16 * US + xoff(mt * 16 + col, n0 % US), acc[nt]);
+            }
+          };
+          if (same_l2) put(std::integral_constant<int, 0>{});
+          else put(std::integral_constant<int, kSC1>{});
         }
       }
       // (B0) [issued behind the MFMA block and the partial-sum stores: nothing waits for it before the end of the step]
@@ -1189,11 +1195,15 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         const f32x4 arm = __builtin_bit_cast(f32x4, (u32x4){kSentinel, kSentinel, kSentinel, kSentinel});
         constexpr int PER = NCL * MT * 16 * US / 4;   // 16-byte pieces of this member's region
         const long rb = (long)((t + 1) % 3) * XSLAB + (long)j * NCL * MT * 16 * US;
+        auto rearm = [&](auto sc) {
 #pragma unroll
-        for (int i = 0; i < (PER + 255) / 256; ++i) {
-          const int pc = tid + 256 * i;
-          if (PER % 256 == 0 || pc < PER) stx4(same_l2, rX, rb + (long)pc * 4, arm);
-        }
+          for (int i = 0; i < (PER + 255) / 256; ++i) {
+            const int pc = tid + 256 * i;
+            if (PER % 256 == 0 || pc < PER) stg4<decltype(sc)::value>(rX, rb + (long)pc * 4, arm);
+          }
+        };
+        if (same_l2) rearm(std::integral_constant<int, 0>{});
+        else rearm(std::integral_constant<int, kSC1>{});
       }
       STAMP(3);
       __syncthreads();   // own columns of dhL visible
@@ -1246,7 +1256,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
             unsigned pend = 0;
 #pragma unroll
             for (int m = 0; m < NCL; ++m)
-              if (m != j && armedn<UI>(v[m])) pend |= 1u << m;
+              if (armedn<UI>(v[m])) pend |= 1u << m;
+            pend &= ~(1u << j);   // the own slot is never written (branch-free: `m != j` inside the loop is a scalar branch per producer)
             unsigned it = 0;
             unsigned long long t0 = 0;
             while (pend) {
