@@ -1168,13 +1168,14 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wbh[nt][s], bh, acc[nt], 0, 0, 0);
           }
+          STAMP(9);
           // lane: batch row `col`, output units n0 .. n0+3.  ONE branch on the store kind around the whole burst (a
           // branch per store: ~20 scalar branches per step in this block alone)
           auto put = [&](auto sc) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
               const int n0 = (wave * NTW + nt) * 16 + q * 4;
-              const int m = n0 / US;
+              const int m = ((wave * NTW + nt) * 16) / US;   // wave-uniform (q * 4 < 16 never changes it): a scalar branch
               if (NCL == 1 || m == j) *reinterpret_cast<f32x4*>(dhL + (mt * 16 + col) * LDH + n0) = acc[nt];
               else stg4<decltype(sc)::value>(rX, (long)par * XSLAB + (long)(m * NCL + j) * MT * 16 * US + xoff(mt * 16 + col, n0 % US), acc[nt]);
             }
@@ -1183,6 +1184,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
           else put(std::integral_constant<int, kSC1>{});
         }
       }
+      STAMP(10);
       // (B0) [issued behind the MFMA block and the partial-sum stores: nothing waits for it before the end of the step]
       // Re-arm what the previous step consumed: this member's whole region of that step's slab -- its own
       // never-written slot included -- as linear 16-byte pieces (whole lines; per-item 8-byte stores to 7 places

@@ -19,7 +19,7 @@ cases = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if not a.star
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 FWD = ["top/rearm/pf", "mfma", "sync1", "publish", "poll", "gates", "vm wait", "pull", "lds+y/stash st", "sync3", "same_l2*1000", "xcc_reg"]
-BWD = ["top", "gate grads+lds+pf", "sync", "mfma+X st", "sync", "dgates st", "poll(w0)", "sync", "reduce-scatter"]
+BWD = ["top", "gate grads+lds+pf", "sync", "re-arm", "sync", "dgates st", "factors", "-", "reduce-scatter", "lds+mfma", "X st"]
 for (B, T, In, H) in cases:
     g = torch.Generator(device="cpu").manual_seed(1)
     k = 1.0 / H ** 0.5
