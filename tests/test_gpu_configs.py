@@ -78,6 +78,9 @@ MORE_LSTM_CASES = [
     # input projection fused into the recurrent kernel (in <= 64, a multiple of 4): one and two x k-steps, in < 32,
     # several tiles per cluster, the padded 36 -> 64 case, hidden 16 / 32
     (40, 9, 4, 16), (300, 21, 12, 32), (530, 17, 36, 64), (1100, 12, 64, 128), (96, 25, 28, 256), (70, 14, 60, 128),
+    # fused hidden-64 layers on partly filled tiles, elementwise part compacted over the idle lanes: 4 valid rows per tile
+    # (one and two x k-steps; (530, 17, 36, 64) above as well), 8 valid rows, and whole tiles
+    (200, 9, 20, 64), (1500, 7, 36, 64), (1500, 6, 32, 64), (3000, 5, 20, 64),
 ]
 
 

@@ -247,7 +247,7 @@ __device__ __forceinline__ bool armed(u32x4 v) {
 // gets XK / 32 more k-steps -- the projection GEMM, its [B][T][4H] output and the kernel's read of it are gone.  Whether
 // a layer is fused depends on (H, in_dim) only, never on the batch: every variant that can serve a layer does the same
 // arithmetic, so a window's result does not depend on the launch it is computed in.
-template <int H, int US, int KS, int MT, int XK>
+template <int H, int US, int KS, int MT, int XK, int CMP = 1>
 __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int NUG = US / 16;          // 16-unit groups per member
   constexpr int NCL = H / US;           // members per cluster
@@ -260,6 +260,14 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // group each take UPW = 4 / KS of a lane's 4 units (they swap the matching parts of their partial
   // sums through LDS), so gate math, publish and pull are spread over all the waves of the workgroup.
   constexpr int UPW = 4 / KS;
+  // CMP > 1 (single-workgroup fused layers whose 16-row tiles hold only 16 / CMP valid rows, see make_plan): the
+  // elementwise part of a step is COMPACTED -- the MFMA leaves a lane (col, q) 4 units of batch row col, of which only
+  // col < 16 / CMP exist; lane col then finishes units sub*UE .. of row col % (16 / CMP), sub = col / (16 / CMP), taking
+  // the sums from lane col % (16 / CMP) of its 16-lane row by DPP.  Every lane works on a unit that exists: a quarter
+  // (CMP = 4) of the exp / rcp work per step, which is what bounds these layers.  Same operations per (row, unit),
+  // same bits.
+  constexpr int UE = UPW / CMP;
+  static_assert(CMP == 1 || (XK > 0 && H / US == 1 && MT == 1 && KS == 1), "compaction: fused single-workgroup one-tile layers only");
   // floats of k-split scratch: [ug][dst][src != dst][lane][4 gates][UPW] (a wave keeps its own part in registers, so
   // there is no [dst][dst] slot: KS - 1 sources per destination, indexed (src - dst - 1) mod KS)
   constexpr int RED = KS > 1 ? NUG * KS * (KS - 1) * 256 * UPW : 0;
@@ -313,7 +321,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const bool active = wave < NACT;
   const int ug = active ? wave % NUG : 0, kp = active ? wave / NUG : 0;
   const int uw = j * US + ug * 16 + col;               // W_hh row (per gate) this lane feeds to the MFMA
-  const int u0 = j * US + ug * 16 + q * 4 + kp * UPW;  // first of the UPW hidden units this lane finishes
+  const int u0m = j * US + ug * 16 + q * 4 + kp * UPW;  // first of the UPW hidden units whose sums the MFMA leaves in this lane
+  const int sub = CMP > 1 ? col / (16 / CMP) : 0;
+  const int rowl = CMP > 1 ? col % (16 / CMP) : col;   // batch row (of the tile) this lane finishes
+  const int u0 = u0m + sub * UE;                       // first of the UE hidden units this lane finishes
   const int b0 = a.b_begin + cl * a.rows;
   const int T = a.T;
   const long rowP = (long)T * 4 * H, rowY = (long)T * H;
@@ -420,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       xstore(1, mt, v1);
     }
   }
-  float c[MT][UPW], pre[MT][4][UPW];
+  float c[MT][UE], pre[MT][4][UPW];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       for (int u = 0; u < UPW; ++u) pre[mt][g][u] = v[u];
     }
 #pragma unroll
-    for (int u = 0; u < UPW; ++u) c[mt][u] = 0.f;
+    for (int u = 0; u < UE; ++u) c[mt][u] = 0.f;
   }
   bool same_l2 = false;
   if (STAGE && !FUSE) {   // step 0's pre-activations into pbuf[0] (the handshake's barriers publish them)
@@ -691,18 +702,18 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           if (m < NCL && m != j) buf[n] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)((sbase + (long)row * H + m * US + c4 * 4) * 4), 0, kSC1);
         }
       }
-      float st[4][UPW], hn[UPW];
+      float st[4][UE], hn[UE];
       if (active) {
-        // (C) gate math, state update, h into LDS and the ring -- UPW consecutive units of one batch row per lane
-        float z[4][UPW];
+        // (C) gate math, state update, h into LDS and the ring -- UE consecutive units of one batch row per lane
+        float z[4][UE];
         if (FUSE) {
           const float* pb = bsum + (u0 - j * US);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const f32x4 w = UPW == 4 ? *reinterpret_cast<const f32x4*>(pb + g * US)
-                                     : (UPW == 2 ? (f32x4){pb[g * US], pb[g * US + 1], 0.f, 0.f} : (f32x4){pb[g * US], 0.f, 0.f, 0.f});
+            const f32x4 w = UE == 4 ? *reinterpret_cast<const f32x4*>(pb + g * US)
+                                    : (UE == 2 ? (f32x4){pb[g * US], pb[g * US + 1], 0.f, 0.f} : (f32x4){pb[g * US], 0.f, 0.f, 0.f});
 #pragma unroll
-            for (int u = 0; u < UPW; ++u) pre[mt][g][u] = w[u];
+            for (int u = 0; u < UE; ++u) pre[mt][g][u] = w[u];
           }
         } else if (STAGE) {
           const float* pb = pbuf + (t & 1) * 16 * PROW + col * PROW + (u0 - j * US);
@@ -713,6 +724,25 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
             pre[mt][g][UPW - 1] = __uint_as_float(w[1]);
           }
         }
+        if constexpr (CMP > 1) {
+          // the sums of this lane's units sit in lane rowl of its 16-lane row, elements sub*UE ..: row_shr by sub * (16 / CMP)
+          auto shr = [](float v, auto n) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + decltype(n)::value, 0xF, 0xF, false)); };
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if constexpr (CMP == 2) {
+#pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const float hi = shr(acc[g][2 + u], std::integral_constant<int, 8>{});
+                z[g][u] = (sub ? hi : acc[g][u]) + pre[mt][g][u];
+              }
+            } else {
+              static_assert(CMP == 2 || CMP == 4, "compaction by 2 or 4");
+              const float s1 = shr(acc[g][1], std::integral_constant<int, 4>{}), s2 = shr(acc[g][2], std::integral_constant<int, 8>{}),
+                          s3 = shr(acc[g][3], std::integral_constant<int, 12>{});
+              z[g][0] = (sub == 0 ? acc[g][0] : (sub == 1 ? s1 : (sub == 2 ? s2 : s3))) + pre[mt][g][0];
+            }
+          }
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -728,7 +758,8 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
                 if (kp == kk) z[g][u] = acc[g][kk * UPW + u] + pre[mt][g][u];
             }
           }
-        if (KS > 1 && (FUSE || t > 0)) {
+        }
+        if constexpr (KS > 1) if (FUSE || t > 0) {
 #pragma unroll
           for (int sr = 0; sr < KS; ++sr) {
             if (sr == kp) continue;
@@ -746,7 +777,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         // single-workgroup layers: the matrix pipe works on this tile's next x part while the VALU does the gate math
         if (XAHEAD && NCL == 1 && t + 1 < T) xraw(t + 1, mt, accx[XAHEAD ? mt : 0]);
 #pragma unroll
-        for (int u = 0; u < UPW; ++u) {
+        for (int u = 0; u < UE; ++u) {
           const float ig = fsig(z[0][u]), fg = fsig(z[1][u]), gg = ftanh(z[2][u]), og = fsig(z[3][u]);
           // explicit fma: left to -ffp-contract the compiler picks either product, differently per instantiation
           const float cn = __builtin_fmaf(fg, c[mt][u], ig * gg);
@@ -756,17 +787,17 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         }
         // h_t of these units: split into bf16 hi / lo for the LDS tile; the ring carries them as one
         // {hi:16 | lo:16} word per element, so the consumers only regroup the halves
-        unsigned short* ph = hiL + (mt * 16 + col) * LDH + u0;
-        unsigned short* pl = loL + (mt * 16 + col) * LDH + u0;
+        unsigned short* ph = hiL + (mt * 16 + rowl) * LDH + u0;
+        unsigned short* pl = loL + (mt * 16 + rowl) * LDH + u0;
         f32x4 hx = {0.f, 0.f, 0.f, 0.f};
-        if (UPW == 4) {
+        if constexpr (UE == 4) {
           u32x2 sh, sl;
           tb_split4((f32x4){hn[0], hn[1], hn[2], hn[3]}, sh, sl);
           *reinterpret_cast<u32x2*>(ph) = sh;
           *reinterpret_cast<u32x2*>(pl) = sl;
           hx = __builtin_bit_cast(f32x4, (u32x4){__builtin_amdgcn_perm(sh[0], sl[0], 0x05040100u), __builtin_amdgcn_perm(sh[0], sl[0], 0x07060302u),
                                                 __builtin_amdgcn_perm(sh[1], sl[1], 0x05040100u), __builtin_amdgcn_perm(sh[1], sl[1], 0x07060302u)});
-        } else if (UPW == 2) {
+        } else if constexpr (UE == 2) {
           unsigned sh, sl;
           tb_split2(hn[0], hn[1], sh, sl);
           *reinterpret_cast<unsigned*>(ph) = sh;
@@ -796,7 +827,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
           stxn<UPW>(same_l2, rR, (long)(t % 3) * RS + (long)(mt * 16 + col) * H + u0, hx);
         }
       }
-      if (STAGE) {
+      if constexpr (STAGE) {
         // y and the stash of this step into sbuf (flushed at the top of the next step; the flush of step t-1 read
         // it before this step's first barrier).  Here rather than after the pull: it ends the life of st / hn
         // before the pull buffers begin theirs.
@@ -893,20 +924,20 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (active && !STAGE) {
         // (E) y for the next layer and the BPTT stash (activated gates over P in place, cell state): after
         // the pull, so that no HBM store sits in front of the hand-off loads
-        f32x4 v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < UPW; ++u) v[u] = hn[u];
-        stgn<UPW, 0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0, v);
+        for (int u = 0; u < UE; ++u) v[u] = hn[u];
+        stgn<UE, 0>(rY, (long)(mt * 16 + rowl) * rowY + (long)t * H + u0, v);
         if (a.train) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
 #pragma unroll
-            for (int u = 0; u < UPW; ++u) v[u] = st[g][u];
-            stgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0, v);
+            for (int u = 0; u < UE; ++u) v[u] = st[g][u];
+            stgn<UE, 0>(rP, (long)(mt * 16 + rowl) * rowP + (long)t * 4 * H + g * H + u0, v);
           }
 #pragma unroll
-          for (int u = 0; u < UPW; ++u) v[u] = c[mt][u];
-          stgn<UPW, 0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0, v);
+          for (int u = 0; u < UE; ++u) v[u] = c[mt][u];
+          stgn<UE, 0>(rC, (long)(mt * 16 + rowl) * rowY + (long)t * H + u0, v);
         }
         if (!FUSE) {
 #pragma unroll
@@ -1508,15 +1539,15 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   return true;
 }
 
-template <int H, int US, int KS, int MT, int XK>
+template <int H, int US, int KS, int MT, int XK, int CMP = 1>
 int launch_fwd_t(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, US, KS, MT, XK>),
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_kernel<H, US, KS, MT, XK, CMP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_fwd_kernel<H, US, KS, MT, XK>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<H, US, KS, MT, XK, CMP>), dim3(grid), dim3(256), lds, s, a);
   TB_LAUNCH_CHECK("lstm_fwd_kernel");
   return TB_OK;
 }
@@ -1553,6 +1584,14 @@ int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
 int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(16, 16, 1, 1); FWD_CASE(16, 16, 1, 2); FWD_CASE(16, 16, 1, 4);
   FWD_CASE(32, 32, 1, 1); FWD_CASE(32, 32, 1, 2); FWD_CASE(32, 32, 1, 4);
+  // fused hidden-64 layers on partly filled tiles (make_plan: 8 or 4 valid rows): the compacted elementwise part
+  static const bool compact = []() { const char* e = getenv("TB_COMPACT"); return !e || atoi(e) != 0; }();   // TB_COMPACT=0: A/B knob
+  if (compact && p.H == 64 && p.MT == 1 && p.XK && a.rows < 16) {
+    if (a.rows == 8 && p.XK == 32) return launch_fwd_t<64, 64, 1, 1, 32, 2>(a, grid, p.lds_fwd, s);
+    if (a.rows == 8 && p.XK == 64) return launch_fwd_t<64, 64, 1, 1, 64, 2>(a, grid, p.lds_fwd, s);
+    if (a.rows == 4 && p.XK == 32) return launch_fwd_t<64, 64, 1, 1, 32, 4>(a, grid, p.lds_fwd, s);
+    if (a.rows == 4 && p.XK == 64) return launch_fwd_t<64, 64, 1, 1, 64, 4>(a, grid, p.lds_fwd, s);
+  }
   FWD_CASE(64, 64, 1, 1); FWD_CASE(64, 64, 1, 2);
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   if (p.US == 64) { FWD_CASE32(256, 64, 1, 1); }
