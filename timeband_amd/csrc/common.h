@@ -35,6 +35,10 @@ int tb_gemm_launch_deferred(const float* A, long lda, int transA, const float* B
                             int M, int N, int K, int b_shift, int b_period, float* ws, size_t ws_bytes, hipStream_t stream,
                             int accumulate, TbGemmDeferred* d);
 
+// losses.hip: column-sum partial pass and the one-launch tail of a linear layer's backward (capi.hip: tb_linear_bwd)
+int tb_colsum_partials(const float* a, long rows, int cols, void* ws, size_t ws_bytes, hipStream_t s, int* nparts);
+int tb_linear_finish(const TbGemmDeferred* d, const double* part, int nparts, int cols, float* db, int accumulate, hipStream_t s);
+
 #define TB_HIP(call)                                   \
   do {                                                 \
     int _rc = tb_check_hip((call), #call);             \

@@ -180,6 +180,41 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const double* __restri
   if (lane == 0) out[c] = accumulate ? out[c] + (float)sh[0] : (float)sh[0];
 }
 
+// Tail of a linear layer's backward in ONE launch (tb_linear_bwd): the split-K slabs of dW = dz^T.x summed in slab order
+// (blocks < dw_blocks, 64 elements each) and the column-sum partials of db summed as colsum_final_kernel does (one
+// block per column behind them).  Either part may be empty.
+__global__ __launch_bounds__(64) void linear_finish_kernel(TbGemmDeferred d, int dw_blocks, const double* __restrict__ part,
+                                                           int nparts, int cols, float* db, int accumulate) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < dw_blocks) {
+    const long n = (long)d.M * d.N, e = (long)blockIdx.x * 64 + lane;
+    if (e < n) {
+      float s = 0.f;
+      for (int z0 = 0; z0 < d.splits; z0 += 8) {   // eight slabs in flight, added in slab order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = z0 + k < d.splits ? d.slab[(size_t)(z0 + k) * n + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+      }
+      float* c = d.C + (e / d.N) * d.ldc + e % d.N;
+      *c = d.accumulate ? *c + s : s;
+    }
+    return;
+  }
+  const int c = blockIdx.x - dw_blocks;
+  double s = 0.0;
+  for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * cols + c];
+  __shared__ double sh[64];
+  sh[lane] = s;
+  __syncthreads();
+  for (int w = 32; w > 0; w >>= 1) {
+    if (lane < w) sh[lane] += sh[lane + w];
+    __syncthreads();
+  }
+  if (lane == 0) db[c] = accumulate ? db[c] + (float)sh[0] : (float)sh[0];
+}
+
 // torch.optim.Adam (no weight decay / amsgrad); operation order follows torch's single-tensor path
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, float one_minus_b1, float b2, float one_minus_b2,
@@ -317,6 +352,40 @@ int tb_colsum_acc(const float* a, long rows, int cols, float* out, int accumulat
   TB_LAUNCH_CHECK("colsum_final_kernel");
   return TB_OK;
 }
+
+}  // extern "C"
+
+// The partial pass of the column sum alone (tb_linear_bwd sums the partials in its finish kernel).
+int tb_colsum_partials(const float* a, long rows, int cols, void* ws, size_t ws_bytes, hipStream_t s, int* nparts) {
+  if (!a || !ws) return tb_set_error(TB_ERR_ARG, "colsum: null pointer");
+  if (ws_bytes < tb_colsum_workspace_bytes(cols)) return tb_set_error(TB_ERR_WORKSPACE, "colsum: workspace too small");
+  int cw = 1;
+  while (cw < cols && cw < 64) cw *= 2;
+  const int ycount = (cols + cw - 1) / cw;
+  long parts = rows / (64L * (256 / cw));
+  const long want = (4L * tb_num_cus() + ycount - 1) / ycount;
+  if (parts > want) parts = want;
+  if (parts > kColsumMaxParts) parts = kColsumMaxParts;
+  if (parts < 1) parts = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((int)parts, ycount), dim3(256), 0, s, a, rows, cols, cw, static_cast<double*>(ws));
+  TB_LAUNCH_CHECK("colsum_kernel");
+  *nparts = (int)parts;
+  return TB_OK;
+}
+
+// d: a deferred dW product (d->splits == 0: nothing pending); part / nparts / cols / db: column-sum partials (db NULL: none)
+int tb_linear_finish(const TbGemmDeferred* d, const double* part, int nparts, int cols, float* db, int accumulate, hipStream_t s) {
+  const long n = d && d->splits ? (long)d->M * d->N : 0;
+  const int dw_blocks = (int)((n + 63) / 64), col_blocks = db ? cols : 0;
+  if (dw_blocks + col_blocks == 0) return TB_OK;
+  TbGemmDeferred dd = {};
+  if (n) dd = *d;
+  hipLaunchKernelGGL(linear_finish_kernel, dim3(dw_blocks + col_blocks), dim3(64), 0, s, dd, dw_blocks, part, nparts, cols, db, accumulate);
+  TB_LAUNCH_CHECK("linear_finish_kernel");
+  return TB_OK;
+}
+
+extern "C" {
 
 int tb_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                  double eps, int step, void* stream) {

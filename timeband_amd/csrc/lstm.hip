@@ -924,20 +924,33 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       if (active && !STAGE) {
         // (E) y for the next layer and the BPTT stash (activated gates over P in place, cell state): after
         // the pull, so that no HBM store sits in front of the hand-off loads
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        // Compacted: the UPW units of a row go back to the lane the MFMA left them in (row_shl within the 16-lane row),
+        // so that y and the stash leave as the same 16-byte stores as from whole tiles (as 4-byte stores from every
+        // lane the kernel alone was as fast, but the iteration around it 1.4 % slower: four times the store
+        // instructions' address work in the memory pipe the co-running kernels share).  Lanes with sub != 0 sit on
+        // rows >= 16 / CMP, which the descriptors drop.
+        auto whole = [&](const float (&src)[UE]) -> f32x4 {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (CMP == 1) {
 #pragma unroll
-        for (int u = 0; u < UE; ++u) v[u] = hn[u];
-        stgn<UE, 0>(rY, (long)(mt * 16 + rowl) * rowY + (long)t * H + u0, v);
+            for (int u = 0; u < UE; ++u) o[u] = src[u];
+          } else {
+            auto shl = [](float v, auto n) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + decltype(n)::value, 0xF, 0xF, false)); };
+            if constexpr (CMP == 2) {
+              o[0] = src[0]; o[1] = src[1];
+              o[2] = shl(src[0], std::integral_constant<int, 8>{}); o[3] = shl(src[1], std::integral_constant<int, 8>{});
+            } else {
+              o[0] = src[0]; o[1] = shl(src[0], std::integral_constant<int, 4>{});
+              o[2] = shl(src[0], std::integral_constant<int, 8>{}); o[3] = shl(src[0], std::integral_constant<int, 12>{});
+            }
+          }
+          return o;
+        };
+        stgn<UPW, 0>(rY, (long)(mt * 16 + col) * rowY + (long)t * H + u0m, whole(hn));
         if (a.train) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int u = 0; u < UE; ++u) v[u] = st[g][u];
-            stgn<UE, 0>(rP, (long)(mt * 16 + rowl) * rowP + (long)t * 4 * H + g * H + u0, v);
-          }
-#pragma unroll
-          for (int u = 0; u < UE; ++u) v[u] = c[mt][u];
-          stgn<UE, 0>(rC, (long)(mt * 16 + rowl) * rowY + (long)t * H + u0, v);
+          for (int g = 0; g < 4; ++g) stgn<UPW, 0>(rP, (long)(mt * 16 + col) * rowP + (long)t * 4 * H + g * H + u0m, whole(st[g]));
+          stgn<UPW, 0>(rC, (long)(mt * 16 + col) * rowY + (long)t * H + u0m, whole(c[mt]));
         }
         if (!FUSE) {
 #pragma unroll
@@ -1368,7 +1381,13 @@ __global__ void wgrad_finish_kernel(WFinishArgs f) {
     } else {
       const int k = (int)(i - n0 - n1);
       float s = 0.f;
-      for (int p = 0; p < f.nparts; ++p) s += f.dbpart[(size_t)p * f.nb + k];
+      for (int p0 = 0; p0 < f.nparts; p0 += 8) {   // eight partials in flight, added in cluster order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p0 + u < f.nparts ? f.dbpart[(size_t)(p0 + u) * f.nb + k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
       if (f.db_ih) f.db_ih[k] = f.db_acc ? f.db_ih[k] + s : s;
       if (f.db_hh) f.db_hh[k] = f.db_acc ? f.db_hh[k] + s : s;
     }
@@ -1412,7 +1431,13 @@ __global__ void wgrad_finish4_kernel(WFinishArgs f) {
     } else if (i < total) {
       const int k = (int)(i - (q0 + q1) * 4);
       float s = 0.f;
-      for (int p = 0; p < f.nparts; ++p) s += f.dbpart[(size_t)p * f.nb + k];
+      for (int p0 = 0; p0 < f.nparts; p0 += 8) {   // eight partials in flight, added in cluster order
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p0 + u < f.nparts ? f.dbpart[(size_t)(p0 + u) * f.nb + k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
       if (f.db_ih) f.db_ih[k] = f.db_acc ? f.db_ih[k] + s : s;
       if (f.db_hh) f.db_hh[k] = f.db_acc ? f.db_hh[k] + s : s;
     }
@@ -1585,8 +1610,8 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(16, 16, 1, 1); FWD_CASE(16, 16, 1, 2); FWD_CASE(16, 16, 1, 4);
   FWD_CASE(32, 32, 1, 1); FWD_CASE(32, 32, 1, 2); FWD_CASE(32, 32, 1, 4);
   // fused hidden-64 layers on partly filled tiles (make_plan: 8 or 4 valid rows): the compacted elementwise part
-  static const bool compact = []() { const char* e = getenv("TB_COMPACT"); return !e || atoi(e) != 0; }();   // TB_COMPACT=0: A/B knob
-  if (compact && p.H == 64 && p.MT == 1 && p.XK && a.rows < 16) {
+  static const int compact = []() { const char* e = getenv("TB_COMPACT"); return e ? atoi(e) : 1; }();   // A/B knob: 0 off, 2 inference only, 3 training only
+  if ((compact == 1 || (compact == 2 && !a.train) || (compact == 3 && a.train)) && p.H == 64 && p.MT == 1 && p.XK && a.rows < 16) {
     if (a.rows == 8 && p.XK == 32) return launch_fwd_t<64, 64, 1, 1, 32, 2>(a, grid, p.lds_fwd, s);
     if (a.rows == 8 && p.XK == 64) return launch_fwd_t<64, 64, 1, 1, 64, 2>(a, grid, p.lds_fwd, s);
     if (a.rows == 4 && p.XK == 32) return launch_fwd_t<64, 64, 1, 1, 32, 4>(a, grid, p.lds_fwd, s);
