@@ -848,6 +848,25 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         // usually finds the data and a poll only added an L2 round trip (2.62 -> 2.48 us/step at hidden 256).
         // Only the ring store above precedes these loads in this wave's memory queue: y and the stash are
         // stored after the pull.
+        // Clusters of more than 8 members (hidden 512: 32 members) keep the poll: with that many producers per wave the
+        // first pull mostly comes back armed and the re-pull loop hammers the ring (5.06 against 4.52 us/step without it).
+        constexpr bool POLL = NCL > 8;
+        if (POLL && MT == 1 && lane < NPP * NUG) {
+          const int m = wave + (lane / NUG) * NPW;
+          if (m < NCL && m != j) {
+            const int voff = (int)((sbase + (long)15 * H + m * US + (lane % NUG) * 16 + 12) * 4);
+            const unsigned long long t0 = wall_clock64();
+            unsigned it = 0;
+            while (armed(__builtin_amdgcn_raw_buffer_load_b128(rR, voff, 0, kSC1))) {
+              __builtin_amdgcn_s_sleep(1);
+              if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
+                atomicExch(a.err, 1);
+                *s_dead = 1;
+                break;
+              }
+            }
+          }
+        }
         STAMP(4);
         // first round without per-lane predicates (which pieces a wave pulls is wave-uniform: straight-line loads, no
         // exec juggling); the loop below only re-pulls what came back armed
@@ -1275,8 +1294,30 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       cprev[n] = nx[n][4];
       dyv[n] = nx[n][5];
     }
-    STAMP(6);
-    STAMP(7);
+    // Clusters of more than 8 members (hidden 512: 32) keep the poll of one piece per producer by one wave, and the
+    // barrier that hands its result to the others: every thread pulling 32 mostly armed pieces over and over costs far
+    // more than the round trip saved (6.19 against 3.83 us/step).
+    constexpr bool POLL = NCL > 8;
+    if constexpr (POLL) {
+      if (wave == 0 && lane < NCL && lane != j) {
+        const int voff = (int)(((long)par * XSLAB + ((long)(j * NCL + lane) * MT * 16 + MT * 16 - 1) * US + US - 4) * 4);
+        const unsigned long long t0 = wall_clock64();
+        unsigned it = 0;
+        while (true) {
+          if (!armed(__builtin_amdgcn_raw_buffer_load_b128(rX, voff, 0, kSC1))) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 1023u) == 0 && wall_clock64() - t0 > a.timeout_ticks) {
+            atomicExch(a.err, 1);
+            *s_dead = 1;
+            break;
+          }
+        }
+      }
+      STAMP(6);
+      __syncthreads();
+      STAMP(7);
+      if (*s_dead) break;
+    }
     // (C) reduce-scatter: dh_{t-1} for this member's units = own partial + the other members' partials
     // (every slot is loaded, the never-written own one included: one predicate-free burst).
     // Data-as-flag: the slabs are armed with the sentinel (all-ones) before the launch, a slot that holds a value is
