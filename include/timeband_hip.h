@@ -133,8 +133,18 @@ int tb_loss_sums(const float* Dy, long nDy, const float* DGx, long nDGx, const f
                  long nP, double* sums, void* ws, size_t ws_bytes, void* stream);
 int tb_loss_finish(const double* sums, int mode, double nD_real, double nD_fake, double nP, double batch,
                    float l1_w, float l2_w, float gp_w, float* out, float* running, float* total, void* stream);
+/* tb_loss_sums + tb_loss_finish in two launches instead of three, for callers with nothing between them (no data-parallel
+ * all-reduce of the sums): same arguments, same results. */
+int tb_loss_sums_finish(const float* Dy, long nDy, const float* DGx, long nDGx, const float* tru, const float* pred, long nP,
+                        double* sums, void* ws, size_t ws_bytes, int mode, double nD_real, double nD_fake, double nP_global,
+                        double batch, float l1_w, float l2_w, float gp_w, float* out, float* running, float* total,
+                        void* stream);
 int tb_gan_loss_grad(const float* p, long n_local, double n_global, int target_is_real, int wgan,
                      const float* upstream, float* dp, void* stream);
+/* tb_gan_loss_grad for the two halves of one buffer p = [D(real) | D(fake)] (n_each elements each, the discriminator's
+ * real + fake pass) in one launch: the real half against the real label, the fake half against the fake one. */
+int tb_gan_loss_grad_pair(const float* p, long n_each, double n_real_global, double n_fake_global, int wgan,
+                          const float* upstream, float* dp, void* stream);
 int tb_recon_loss_grad(const float* tru, const float* pred, long n_local, double n_global, double batch,
                        const double* sums, float l1_w, float l2_w, float gp_w, const float* upstream,
                        float* dpred, int accumulate, void* stream);

@@ -443,3 +443,33 @@ def test_pair_pass_skips_only_the_real_half_input_gradient(dev):
     assert torch.equal(ga, gb)
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("critic", [False, True])
+def test_pair_loss_gradient_in_one_launch_equals_two(dev, critic):
+    """dis_loss on the two halves of the discriminator's real + fake output sends the gradient to their common
+    buffer in one launch (ops._pair_base / tb_gan_loss_grad_pair): same loss, same gradients, bit for bit, as the
+    two-launch path that copies of the halves take."""
+    from timeband_amd import ops
+    V, E, To, Tf, H, L = 8, 12, 24, 24, 128, 1
+    netD, _ = make_nets(V, E, To, Tf, H, L, dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    real = (torch.rand(40, Tf, V, generator=g) * 2 - 1).to(dev)
+    fake = (torch.rand(40, Tf, V, generator=g) * 2 - 1).to(dev)
+
+    def run(paired):
+        netD.zero_grad(set_to_none=True)
+        f = fake.clone().requires_grad_()
+        Dy, DGx = netD.pair(real, f)
+        assert ops._pair_base(Dy, DGx) is not None
+        if not paired:
+            Dy, DGx = Dy.clone(), DGx.clone()
+            assert ops._pair_base(Dy, DGx) is None
+        total, out = ops.dis_loss(Dy, DGx, real if critic else None, f if critic else None, critic, 10.0 if critic else 0.0, None)
+        total.backward()
+        return total.detach().clone(), out.clone(), f.grad.clone(), [p.grad.clone() for p in netD.parameters()]
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for x, y in zip(a[3], b[3]):
+        assert torch.equal(x, y)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "tb_loss_workspace_bytes": (Z, []),
     "tb_loss_sums": (I, [P, L, P, L, P, P, L, P, P, Z, P]),
     "tb_loss_finish": (I, [P, I, D, D, D, D, F, F, F, P, P, P, P]),
+    "tb_loss_sums_finish": (I, [P, L, P, L, P, P, L, P, P, Z, I, D, D, D, D, F, F, F, P, P, P, P]),
+    "tb_gan_loss_grad_pair": (I, [P, L, D, D, I, P, P, P]),
     "tb_gan_loss_grad": (I, [P, L, D, I, I, P, P, P]),
     "tb_recon_loss_grad": (I, [P, P, L, D, D, P, F, F, F, P, P, I, P]),
     "tb_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),

@@ -75,10 +75,8 @@ __global__ void loss_final_kernel(const double* __restrict__ part, int nblocks, 
 // mode 1: critic WGAN + GP      out = [total, real, fake, gp]
 // mode 2: generator             out = [total, adv, l1, l2, gp]
 // running (nullable, float[8]): D: [0]+=real [1]+=fake ; G: [2]+=adv [3]+=l1 [4]+=l2 [5]+=gp
-__global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, double nD_real, double nD_fake,
-                                   double nP, double batch, float l1_w, float l2_w, float gp_w, float* out,
-                                   float* running, float* total) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void loss_finish_dev(const double* sums, int mode, double nD_real, double nD_fake, double nP, double batch,
+                                float l1_w, float l2_w, float gp_w, float* out, float* running, float* total) {
   if (mode == 0) {
     const float real = (float)(sums[0] / nD_real), fake = (float)(sums[1] / nD_fake);
     out[0] = fake + real; out[1] = real; out[2] = fake; out[3] = 0.f;
@@ -98,6 +96,40 @@ __global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, do
     if (running) { running[2] += adv; running[3] += l1; running[4] += l2; running[5] += gp; }
   }
   if (total) total[0] = out[0];
+}
+
+__global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, double nD_real, double nD_fake,
+                                   double nP, double batch, float l1_w, float l2_w, float gp_w, float* out,
+                                   float* running, float* total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  loss_finish_dev(sums, mode, nD_real, nD_fake, nP, batch, l1_w, l2_w, gp_w, out, running, total);
+}
+
+// loss_final_kernel and loss_finish_kernel in one launch (tb_loss_sums_finish: no all-reduce between them)
+__global__ void loss_final_finish_kernel(const double* __restrict__ part, int nblocks, double* sums, int mode,
+                                         double nD_real, double nD_fake, double nP, double batch, float l1_w, float l2_w,
+                                         float gp_w, float* out, float* running, float* total) {
+  __shared__ double sh[8];
+  __shared__ double fin[NSUM];
+  for (int k = 0; k < NSUM; ++k) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[(size_t)b * NSUM + k];
+    const double r = block_sum(v, sh);
+    if (threadIdx.x == 0) { sums[k] = r; fin[k] = r; }
+  }
+  if (threadIdx.x == 0) loss_finish_dev(fin, mode, nD_real, nD_fake, nP, batch, l1_w, l2_w, gp_w, out, running, total);
+}
+
+// both halves of the discriminator's real + fake output in one launch: p = [real half | fake half], n each
+__global__ void gan_grad_pair_kernel(const float* __restrict__ p, long n_each, double n_real_global, double n_fake_global,
+                                     int wgan, const float* __restrict__ upstream, float* __restrict__ dp) {
+  const float up = upstream ? upstream[0] : 1.f;
+  const float inv_r = (float)(1.0 / n_real_global), inv_f = (float)(1.0 / n_fake_global);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n_each; i += (long)gridDim.x * blockDim.x) {
+    const bool real = i < n_each;
+    const float label = real ? 0.9f : 0.1f, sign = real ? -1.f : 1.f, inv = real ? inv_r : inv_f;
+    dp[i] = wgan ? up * sign * inv : up * 2.f * (p[i] - label) * inv;
+  }
 }
 
 // d(loss)/dD for the adversarial terms.  lsgan: up * 2 (p - label) / n ; wgan: up * sign / n
@@ -283,6 +315,39 @@ int tb_loss_finish(const double* sums, int mode, double nD_real, double nD_fake,
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, s, sums, mode, nD_real, nD_fake, nP, batch, l1_w,
                      l2_w, gp_w, out, running, total);
   TB_LAUNCH_CHECK("loss_finish_kernel");
+  return TB_OK;
+}
+
+int tb_loss_sums_finish(const float* Dy, long nDy, const float* DGx, long nDGx, const float* tru, const float* pred, long nP,
+                        double* sums, void* ws, size_t ws_bytes, int mode, double nD_real, double nD_fake, double nP_global,
+                        double batch, float l1_w, float l2_w, float gp_w, float* out, float* running, float* total,
+                        void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!sums || !ws || !out) return tb_set_error(TB_ERR_ARG, "loss_sums_finish: null pointer");
+  if (ws_bytes < tb_loss_workspace_bytes()) return tb_set_error(TB_ERR_WORKSPACE, "loss_sums_finish: workspace too small");
+  long nmax = nDy > nDGx ? nDy : nDGx;
+  if (nP > nmax) nmax = nP;
+  const int blocks = grid_for(nmax, 1024);
+  double* part = static_cast<double*>(ws);
+  tb_prof_begin(TB_K_LOSS, s);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, s, Dy, nDy, DGx, nDGx, tru, pred, nP, 0.9f,
+                     0.1f, part);
+  TB_LAUNCH_CHECK("loss_partial_kernel");
+  hipLaunchKernelGGL(loss_final_finish_kernel, dim3(1), dim3(256), 0, s, part, blocks, sums, mode, nD_real, nD_fake,
+                     nP_global, batch, l1_w, l2_w, gp_w, out, running, total);
+  TB_LAUNCH_CHECK("loss_final_finish_kernel");
+  tb_prof_end(TB_K_LOSS, s);
+  return TB_OK;
+}
+
+int tb_gan_loss_grad_pair(const float* p, long n_each, double n_real_global, double n_fake_global, int wgan,
+                          const float* upstream, float* dp, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n_each <= 0) return TB_OK;
+  if (!dp || (!wgan && !p)) return tb_set_error(TB_ERR_ARG, "gan_loss_grad_pair: null pointer");
+  hipLaunchKernelGGL(gan_grad_pair_kernel, dim3(grid_for(2 * n_each)), dim3(256), 0, s, p, n_each, n_real_global,
+                     n_fake_global, wgan, upstream, dp);
+  TB_LAUNCH_CHECK("gan_grad_pair_kernel");
   return TB_OK;
 }
 

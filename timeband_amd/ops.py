@@ -404,6 +404,32 @@ def _loss_sums(Dy, DGx, tru, pred, rt, reduce=True):
     return sums
 
 
+def _loss_sums_finish(Dy, DGx, tru, pred, rt, mode, nD_real, nD_fake, nP, batch, l1_w, l2_w, gp_w, out, running, total):
+    """_loss_sums + tb_loss_finish with nothing between them (no all-reduce of the sums): two launches instead of three."""
+    lib = _lib.load()
+    sums = torch.empty(8, dtype=torch.float64, device=rt.device)
+    ws = rt.workspace(lib.tb_loss_workspace_bytes())
+    _lib.call("tb_loss_sums_finish", _ptr(Dy), 0 if Dy is None else Dy.numel(), _ptr(DGx),
+              0 if DGx is None else DGx.numel(), _ptr(tru), _ptr(pred), 0 if pred is None else pred.numel(),
+              _ptr(sums), _ptr(ws), ws.numel(), mode, nD_real, nD_fake, nP, batch, float(l1_w), float(l2_w), float(gp_w),
+              _ptr(out), _ptr(running), _ptr(total), _stream())
+    return sums
+
+
+def _pair_base(Dy, DGx):
+    """The discriminator's real + fake pass returns its two halves as views of ONE output buffer: that buffer (the
+    autograd root both are views of) if Dy and DGx are exactly its first and second half, else None."""
+    base = getattr(Dy, "_base", None)
+    if base is None or base is not getattr(DGx, "_base", None) or not base.is_contiguous() or base.dtype != torch.float32:
+        return None
+    n = Dy.numel()
+    if DGx.numel() != n or base.numel() != 2 * n or not (Dy.is_contiguous() and DGx.is_contiguous()):
+        return None
+    if Dy.data_ptr() != base.data_ptr() or DGx.data_ptr() != base.data_ptr() + 4 * n:
+        return None
+    return base
+
+
 class ReconPresum:
     """sum huber(pred - true), sum (pred - true)^2 of this rank's windows, all-reduce in flight."""
 
@@ -429,25 +455,31 @@ class _DisLossFn(torch.autograd.Function):
     """TIMEBANDLoss.dis_loss (loss.py:106-119): returns (total, out[8]); out is not differentiable."""
 
     @staticmethod
-    def forward(ctx, Dy, DGx, tru, pred, critic, gp_w, running):
+    def forward(ctx, Dy, DGx, tru, pred, critic, gp_w, running, base):
+        # base: the buffer Dy and DGx are the two halves of (_pair_base), or None.  With it the gradient goes to that
+        # buffer in ONE launch -- instead of two, plus autograd's concatenation of the halves behind them
         _need_cuda(Dy, DGx, tru, pred)
         Dy, DGx = _f32c(Dy), _f32c(DGx)
         rt = Runtime.get(Dy.device)
-        if critic:
-            tru, pred = _f32c(tru), _f32c(pred)
-            # the penalty's gradient needs the global norm; without it (the trainer's critic step runs G without
-            # a graph) nothing does, and the critic's loss value -- never logged, loss.py:107-112 -- stays local
-            sums = _loss_sums(Dy, DGx, tru, pred, rt, reduce=bool(ctx.needs_input_grad[3]))
-        else:
-            sums = _loss_sums(Dy, DGx, None, None, rt, reduce=False)
         out = torch.empty(8, dtype=torch.float32, device=Dy.device)
         nP = dp.count_scale(pred.numel()) if critic else 1.0
         batch = dp.count_scale(tru.shape[0]) if critic else 1.0
         nDy, nDGx = dp.count_scale(Dy.numel()), dp.count_scale(DGx.numel())
-        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs
-        _lib.call("tb_loss_finish", _ptr(sums), 1 if critic else 0, nDy, nDGx,  # must not alias each other
-                  nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), _ptr(None if critic else running), _ptr(total), _stream())
+        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs must not alias
+        if critic:
+            tru, pred = _f32c(tru), _f32c(pred)
+        # the penalty's gradient needs the global norm; without it (the trainer's critic step runs G without
+        # a graph) nothing does, and the critic's loss value -- never logged, loss.py:107-112 -- stays local
+        if critic and ctx.needs_input_grad[3] and dp.active():
+            sums = _loss_sums(Dy, DGx, tru, pred, rt, reduce=True)
+            _lib.call("tb_loss_finish", _ptr(sums), 1, nDy, nDGx, nP, batch, 0.0, 0.0, float(gp_w), _ptr(out), 0,
+                      _ptr(total), _stream())
+        else:
+            sums = _loss_sums_finish(Dy, DGx, tru if critic else None, pred if critic else None, rt, 1 if critic else 0,
+                                     nDy, nDGx, nP, batch, 0.0, 0.0, gp_w, out, None if critic else running, total)
         ctx.critic, ctx.gp_w, ctx.counts = critic, gp_w, (nDy, nDGx, nP, batch)
+        ctx.paired = base is not None
+        ctx.base_shape = None if base is None else tuple(base.shape)
         ctx.save_for_backward(Dy, DGx, tru if critic else None, pred if critic else None, sums)
         ctx.mark_non_differentiable(out)
         ctx.set_materialize_grads(False)     # no zero-fill launch for `out`'s unused gradient
@@ -456,13 +488,18 @@ class _DisLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gtotal, _gout):
         if gtotal is None:
-            return (None,) * 7
+            return (None,) * 8
         Dy, DGx, tru, pred, sums = ctx.saved_tensors
         nDy, nDGx, nP, batch = ctx.counts
         up = _f32c(gtotal)
-        dDy = torch.empty_like(Dy) if ctx.needs_input_grad[0] else None
-        dDGx = torch.empty_like(DGx) if ctx.needs_input_grad[1] else None
         wgan = 1 if ctx.critic else 0
+        dbase = None
+        if ctx.paired and ctx.needs_input_grad[7]:
+            # Dy is the first half of the buffer, DGx the second (checked by _pair_base)
+            dbase = torch.empty(ctx.base_shape, dtype=torch.float32, device=Dy.device)
+            _lib.call("tb_gan_loss_grad_pair", _ptr(Dy), Dy.numel(), nDy, nDGx, wgan, _ptr(up), _ptr(dbase), _stream())
+        dDy = torch.empty_like(Dy) if ctx.needs_input_grad[0] and not ctx.paired else None
+        dDGx = torch.empty_like(DGx) if ctx.needs_input_grad[1] and not ctx.paired else None
         if dDy is not None:
             _lib.call("tb_gan_loss_grad", _ptr(Dy), Dy.numel(), nDy, 1, wgan, _ptr(up), _ptr(dDy), _stream())
         if dDGx is not None:
@@ -472,7 +509,7 @@ class _DisLossFn(torch.autograd.Function):
             dpred = torch.empty_like(pred)
             _lib.call("tb_recon_loss_grad", _ptr(tru), _ptr(pred), pred.numel(), nP, batch, _ptr(sums), 0.0, 0.0,
                       float(ctx.gp_w), _ptr(up), _ptr(dpred), 0, _stream())
-        return dDy, dDGx, None, dpred, None, None, None
+        return dDy, dDGx, None, dpred, None, None, None, dbase
 
 
 class _GenLossFn(torch.autograd.Function):
@@ -486,15 +523,19 @@ class _GenLossFn(torch.autograd.Function):
         if presum is not None:
             sums = _loss_sums(None, DGx, None, None, rt, reduce=False)
             sums[4:6].copy_(presum.get()[4:6])      # the global reconstruction sums, reduced under the D pass
-        else:
+        elif dp.active():
             sums = _loss_sums(None, DGx, tru, pred, rt, reduce=False)
-            if dp.active():
-                dp.all_reduce(sums[4:6])
+            dp.all_reduce(sums[4:6])
+        else:
+            sums = None
         out = torch.empty(8, dtype=torch.float32, device=pred.device)
         nDGx, nP, batch = dp.count_scale(DGx.numel()), dp.count_scale(pred.numel()), dp.count_scale(tru.shape[0])
-        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs
-        _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, nDGx, nP, batch, float(l1_w), float(l2_w), float(gp_w),
-                  _ptr(out), _ptr(running), _ptr(total), _stream())             # must not alias each other
+        total = torch.empty((), dtype=torch.float32, device=out.device)    # separate storage: autograd outputs must not alias
+        if sums is None:
+            sums = _loss_sums_finish(None, DGx, tru, pred, rt, 2, 1.0, nDGx, nP, batch, l1_w, l2_w, gp_w, out, running, total)
+        else:
+            _lib.call("tb_loss_finish", _ptr(sums), 2, 1.0, nDGx, nP, batch, float(l1_w), float(l2_w), float(gp_w),
+                      _ptr(out), _ptr(running), _ptr(total), _stream())
         ctx.w = (l1_w, l2_w, gp_w)
         ctx.counts = (nDGx, nP, batch)
         ctx.save_for_backward(tru, pred, DGx, sums)
@@ -522,7 +563,11 @@ class _GenLossFn(torch.autograd.Function):
 
 
 def dis_loss(Dy, DGx, tru=None, pred=None, critic=False, gp_w=0.0, running=None):
-    return _DisLossFn.apply(Dy, DGx, tru, pred, critic, gp_w, running)
+    base = _pair_base(Dy, DGx) if (Dy.requires_grad and DGx.requires_grad and torch.is_grad_enabled()) else None
+    if base is not None:
+        # the halves enter as data, the gradient leaves through the buffer they are views of
+        return _DisLossFn.apply(Dy.detach(), DGx.detach(), tru, pred, critic, gp_w, running, base)
+    return _DisLossFn.apply(Dy, DGx, tru, pred, critic, gp_w, running, None)
 
 
 def gen_loss(tru, pred, DGx, l1_w, l2_w, gp_w, running=None, presum=None):

@@ -245,7 +245,7 @@ class TIMEBANDTrainer:
                     dphase = None
                 # data parallel: the all-reduce of the gradient-penalty norm's sums starts here and runs under
                 # the discriminator pass below
-                presum = self.losses.recon_presum(true_y, fake_y) if training else None
+                presum = self.losses.recon_presum(true_y, fake_y) if training and dp.active() else None
                 if training:
                     # Adam(D) after the D-phase backward (trainer.py:179-180), placed behind the generator forward
                     # -- which does not read D -- so that D's gradient all-reduce hides under it
