@@ -470,6 +470,7 @@ def test_pair_loss_gradient_in_one_launch_equals_two(dev, critic):
         return total.detach().clone(), out.clone(), f.grad.clone(), [p.grad.clone() for p in netD.parameters()]
 
     a, b = run(True), run(False)
-    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    # (the logging vector has four entries for the discriminator's losses; the rest of its eight floats is never written)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1][:4], b[1][:4]) and torch.equal(a[2], b[2])
     for x, y in zip(a[3], b[3]):
         assert torch.equal(x, y)

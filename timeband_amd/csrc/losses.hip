@@ -109,14 +109,15 @@ __global__ void loss_finish_kernel(const double* __restrict__ sums, int mode, do
 __global__ void loss_final_finish_kernel(const double* __restrict__ part, int nblocks, double* sums, int mode,
                                          double nD_real, double nD_fake, double nP, double batch, float l1_w, float l2_w,
                                          float gp_w, float* out, float* running, float* total) {
-  __shared__ double sh[8];
+  // 512 threads: wave k sums the partials of sum k (lanes stride the blocks, then a fixed-order tree) -- the eight sums
+  // side by side instead of eight block reductions in a row
   __shared__ double fin[NSUM];
-  for (int k = 0; k < NSUM; ++k) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) v += part[(size_t)b * NSUM + k];
-    const double r = block_sum(v, sh);
-    if (threadIdx.x == 0) { sums[k] = r; fin[k] = r; }
-  }
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double v = 0.0;
+  for (int b = lane; b < nblocks; b += 64) v += part[(size_t)b * NSUM + k];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if (lane == 0) { sums[k] = v; fin[k] = v; }
+  __syncthreads();
   if (threadIdx.x == 0) loss_finish_dev(fin, mode, nD_real, nD_fake, nP, batch, l1_w, l2_w, gp_w, out, running, total);
 }
 
@@ -212,39 +213,43 @@ __global__ __launch_bounds__(64) void colsum_final_kernel(const double* __restri
   if (lane == 0) out[c] = accumulate ? out[c] + (float)sh[0] : (float)sh[0];
 }
 
-// Tail of a linear layer's backward in ONE launch (tb_linear_bwd): the split-K slabs of dW = dz^T.x summed in slab order
-// (blocks < dw_blocks, 64 elements each) and the column-sum partials of db summed as colsum_final_kernel does (one
-// block per column behind them).  Either part may be empty.
-__global__ __launch_bounds__(64) void linear_finish_kernel(TbGemmDeferred d, int dw_blocks, const double* __restrict__ part,
-                                                           int nparts, int cols, float* db, int accumulate) {
-  const int lane = threadIdx.x;
+// Tail of a linear layer's backward in ONE launch (tb_linear_bwd): the split-K slabs of dW = dz^T.x summed in a fixed
+// order (blocks < dw_blocks: 8 lanes per element, lane l takes slabs l, l + 8, ... four loads in flight, then a butterfly
+// over the 8 lanes -- a one-tile product over K = 131072 comes in 512 slabs) and the column-sum partials of db summed as
+// colsum_final_kernel does (one block per column behind them, its first wave).  Either part may be empty.
+__global__ __launch_bounds__(256) void linear_finish_kernel(TbGemmDeferred d, int dw_blocks, const double* __restrict__ part,
+                                                            int nparts, int cols, float* db, int accumulate) {
   if ((int)blockIdx.x < dw_blocks) {
-    const long n = (long)d.M * d.N, e = (long)blockIdx.x * 64 + lane;
+    const long n = (long)d.M * d.N, i = (long)blockIdx.x * 256 + threadIdx.x, e = i >> 3;
+    const int l = (int)(i & 7);
+    float s = 0.f;
     if (e < n) {
-      float s = 0.f;
-      for (int z0 = 0; z0 < d.splits; z0 += 8) {   // eight slabs in flight, added in slab order
-        float v[8];
+      int z = l;
+      for (; z + 24 < d.splits; z += 32) {
+        float v[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = z0 + k < d.splits ? d.slab[(size_t)(z0 + k) * n + e] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = d.slab[(size_t)(z + 8 * k) * n + e];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s += v[k];
+        for (int k = 0; k < 4; ++k) s += v[k];
       }
+      for (; z < d.splits; z += 8) s += d.slab[(size_t)z * n + e];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (e < n && l == 0) {
       float* c = d.C + (e / d.N) * d.ldc + e % d.N;
       *c = d.accumulate ? *c + s : s;
     }
     return;
   }
+  const int lane = threadIdx.x;
+  if (lane >= 64) return;
   const int c = blockIdx.x - dw_blocks;
   double s = 0.0;
   for (int p = lane; p < nparts; p += 64) s += part[(size_t)p * cols + c];
-  __shared__ double sh[64];
-  sh[lane] = s;
-  __syncthreads();
-  for (int w = 32; w > 0; w >>= 1) {
-    if (lane < w) sh[lane] += sh[lane + w];
-    __syncthreads();
-  }
-  if (lane == 0) db[c] = accumulate ? db[c] + (float)sh[0] : (float)sh[0];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);   // one wave: a fixed-order tree
+  if (lane == 0) db[c] = accumulate ? db[c] + (float)s : (float)s;
 }
 
 // torch.optim.Adam (no weight decay / amsgrad); operation order follows torch's single-tensor path
@@ -333,7 +338,8 @@ int tb_loss_sums_finish(const float* Dy, long nDy, const float* DGx, long nDGx, 
   hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, s, Dy, nDy, DGx, nDGx, tru, pred, nP, 0.9f,
                      0.1f, part);
   TB_LAUNCH_CHECK("loss_partial_kernel");
-  hipLaunchKernelGGL(loss_final_finish_kernel, dim3(1), dim3(256), 0, s, part, blocks, sums, mode, nD_real, nD_fake,
+  static_assert(NSUM == 8, "loss_final_finish_kernel: one wave per sum");
+  hipLaunchKernelGGL(loss_final_finish_kernel, dim3(1), dim3(512), 0, s, part, blocks, sums, mode, nD_real, nD_fake,
                      nP_global, batch, l1_w, l2_w, gp_w, out, running, total);
   TB_LAUNCH_CHECK("loss_final_finish_kernel");
   tb_prof_end(TB_K_LOSS, s);
@@ -441,11 +447,11 @@ int tb_colsum_partials(const float* a, long rows, int cols, void* ws, size_t ws_
 // d: a deferred dW product (d->splits == 0: nothing pending); part / nparts / cols / db: column-sum partials (db NULL: none)
 int tb_linear_finish(const TbGemmDeferred* d, const double* part, int nparts, int cols, float* db, int accumulate, hipStream_t s) {
   const long n = d && d->splits ? (long)d->M * d->N : 0;
-  const int dw_blocks = (int)((n + 63) / 64), col_blocks = db ? cols : 0;
+  const int dw_blocks = (int)((n * 8 + 255) / 256), col_blocks = db ? cols : 0;
   if (dw_blocks + col_blocks == 0) return TB_OK;
   TbGemmDeferred dd = {};
   if (n) dd = *d;
-  hipLaunchKernelGGL(linear_finish_kernel, dim3(dw_blocks + col_blocks), dim3(64), 0, s, dd, dw_blocks, part, nparts, cols, db, accumulate);
+  hipLaunchKernelGGL(linear_finish_kernel, dim3(dw_blocks + col_blocks), dim3(256), 0, s, dd, dw_blocks, part, nparts, cols, db, accumulate);
   TB_LAUNCH_CHECK("linear_finish_kernel");
   return TB_OK;
 }
