@@ -38,10 +38,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     wv[c] = k < K ? *reinterpret_cast<const f32x4*>(w + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const float bias = b ? b[0] : 0.f;
-  for (long r0 = wave * 4; r0 < M; r0 += nwaves * 4) {   // 4 rows per pass: 4 independent 1 KB loads in flight
-    float acc[4];
+  // 8 rows per pass: 8 independent 1 KB loads in flight per wave, then ONE transposed butterfly for the eight row sums (the
+  // xor-32 / 16 / 8 steps each hand half of the rows to the partner lane: 4 + 2 + 1 shuffles, then 3 for the last value,
+  // instead of 8 x 6).  Every row's sum is added up along the same tree as a plain xor butterfly, so a row's result does
+  // not depend on the slot it sits in.
+  const bool b32 = lane & 32, b16 = lane & 16, b8 = lane & 8;
+  for (long r0 = wave * 8; r0 < M; r0 += nwaves * 8) {
+    float acc[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       acc[i] = 0.f;
       const long r = r0 + i;
 #pragma unroll
@@ -53,11 +58,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         }
       }
     }
+    float h4[4], h2[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float s = wave_sum(acc[i]);
-      if (lane == 0 && r0 + i < M) out[r0 + i] = act_fwd(s + bias, act);
-    }
+    for (int k = 0; k < 4; ++k) h4[k] = (b32 ? acc[4 + k] : acc[k]) + __shfl_xor(b32 ? acc[k] : acc[4 + k], 32, 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) h2[k] = (b16 ? h4[2 + k] : h4[k]) + __shfl_xor(b16 ? h4[k] : h4[2 + k], 16, 64);
+    float v = (b8 ? h2[1] : h2[0]) + __shfl_xor(b8 ? h2[0] : h2[1], 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    const long r = r0 + (b32 ? 4 : 0) + (b16 ? 2 : 0) + (b8 ? 1 : 0);
+    if ((lane & 7) == 0 && r < M) out[r] = act_fwd(v + bias, act);
   }
 }
 
@@ -137,6 +148,12 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
   }
 }
 
+int head_blocks_fwd(long M) {   // 8 rows per wave and pass
+  long b = (M + 31) / 32;
+  const long cap = 4L * tb_num_cus();
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
 int head_blocks(long M) {
   long b = (M + 15) / 16;
   const long cap = 2L * tb_num_cus();
@@ -158,7 +175,7 @@ int tb_head_fwd(const float* x, const float* w, const float* b, float* out, long
   if (!tb_head_supported(K)) return tb_set_error(TB_ERR_UNSUPPORTED, "head_fwd: K=%d (needs K %% 4 == 0, K <= 1024)", K);
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15)
     return tb_set_error(TB_ERR_ARG, "head_fwd: x and w must be 16-byte aligned");
-  const int nc = (K + 255) / 256, grid = head_blocks(M);
+  const int nc = (K + 255) / 256, grid = head_blocks_fwd(M);
   if (nc == 1) hipLaunchKernelGGL(head_fwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, w, b, out, M, K, act);
   else if (nc == 2) hipLaunchKernelGGL(head_fwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, w, b, out, M, K, act);
   else hipLaunchKernelGGL(head_fwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, w, b, out, M, K, act);
