@@ -89,27 +89,34 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     wv[c] = (dx && k < K) ? *reinterpret_cast<const f32x4*>(w + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
     dwa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (long r0 = wave * 4; r0 < M; r0 += nwaves * 4) {
+  // 8 rows per pass, every load requested before the first use (with an early `break` per row the compiler issued one
+  // row's loads at a time); rows are accumulated in row order, as before
+  constexpr int RP = 8;
+  for (long r0 = wave * RP; r0 < M; r0 += nwaves * RP) {
+    float dz[RP];
+    f32x4 xv[RP][NC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RP; ++i) {
       const long r = r0 + i;
-      if (r >= M) break;
-      float dz = dy[r];
-      if (act) {
-        const float y = out[r];
-        dz *= act == 1 ? (1.f - y * y) : y * (1.f - y);
-      }
-      dba += dz;
+      const bool ok = r < M;
+      dz[i] = ok ? dy[r] : 0.f;
+      const float y = (ok && act) ? out[r] : 0.f;
+      if (act) dz[i] *= act == 1 ? (1.f - y * y) : y * (1.f - y);
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int k = (c * 64 + lane) * 4;
-        if (k < K) {
-          if (need_dw) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * K + k);
-            dwa[c] += xv * dz;
-          }
-          if (dx) *reinterpret_cast<f32x4*>(dx + r * K + k) = wv[c] * dz;
-        }
+        xv[i][c] = (need_dw && ok && k < K) ? *reinterpret_cast<const f32x4*>(x + r * K + k) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      const long r = r0 + i;
+      dba += dz[i];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int k = (c * 64 + lane) * 4;
+        dwa[c] += xv[i][c] * dz[i];
+        if (dx && r < M && k < K) *reinterpret_cast<f32x4*>(dx + r * K + k) = wv[c] * dz[i];
       }
     }
   }

@@ -33,3 +33,19 @@ for M in (65536, 131072):
                 ops.linear_act(x, W, b, ops.ACT_SIGMOID)
         f = t(fresh)
     print(f"M={M}: warm {warm:.1f} us  after 512MB flush {c:.1f} us  x just rewritten {f:.1f} us  ({M*K*4/1e6:.0f} MB)")
+
+# backward: dx + dW + db
+for M in (65536, 131072):
+    x = torch.randn(M, K, device=dev, requires_grad=True)
+    Wp, bp = W.clone().requires_grad_(), b.clone().requires_grad_()
+    dy = torch.randn(M, 1, device=dev)
+    tot = 0.0
+    for i in range(7):
+        y = ops.linear_act(x, Wp, bp, ops.ACT_SIGMOID)
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); y.backward(dy); e.record(); torch.cuda.synchronize()
+        if i >= 2:
+            tot += a.elapsed_time(e)
+        x.grad = None
+    print(f"M={M}: backward {tot / 5 * 1e3:.1f} us (through autograd)")
