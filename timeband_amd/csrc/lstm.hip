@@ -1158,10 +1158,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
         const int row = (e / QPR) & 15, mt = e / (16 * QPR);
         const long rr = mt * 16 + row;
         const bool ok = e < NE;
+        // branch-free: an item that does not exist (or step -1) asks for an offset past the descriptor's end, which returns 0
+        constexpr long kOut = 0x1FFFFFFFl;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) nx[n][g] = ok ? ldgn<UI, 0>(rG, rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0) : zero4;
-        nx[n][4] = (ok && t > 1) ? ldgn<UI, 0>(rC, rr * rowY + (long)(t - 2) * H + uabs0) : zero4;
-        nx[n][5] = ok ? ldgn<UI, 0>(rD, rr * rowY + (long)(t - 1) * H + uabs0) : zero4;
+        for (int g = 0; g < 4; ++g) nx[n][g] = ldgn<UI, 0>(rG, ok ? rr * rowG + (long)(t - 1) * 4 * H + g * H + uabs0 : kOut);
+        nx[n][4] = ldgn<UI, 0>(rC, (ok && t > 1) ? rr * rowY + (long)(t - 2) * H + uabs0 : kOut);
+        nx[n][5] = ldgn<UI, 0>(rD, ok ? rr * rowY + (long)(t - 1) * H + uabs0 : kOut);
       }
     }
     // (A) gate gradients for this member's units
