@@ -64,7 +64,9 @@ int tb_lstm_bwd(const float* dy, const float* x, const float* w_ih, const float*
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,
                 int* err, void* stream);
 /* tb_lstm_bwd with dx computed for the batch rows [dx_row_begin, B) only (rows before are left untouched): the
- * discriminator's real + fake pass reads the input gradient of the fake half alone (trainer.py:174-180). */
+ * discriminator's real + fake pass reads the input gradient of the fake half alone (trainer.py:174-180).
+ * (Both: for clustered layers with in_dim <= 32, a multiple of 4, dx is computed inside the BPTT kernel -- partials per
+ * cluster member in the workspace, summed by a small kernel -- instead of by a GEMM over the dgates matrix.) */
 int tb_lstm_bwd_rows(const float* dy, const float* x, const float* w_ih, const float* w_hh, const float* y,
                 float* gates, const float* cstash, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
                 float* db_hh, int B, int T, int in_dim, int H, int accumulate, void* ws, size_t ws_bytes,

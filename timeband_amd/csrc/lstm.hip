@@ -1005,9 +1005,16 @@ struct BwdArgs {
   int cl_begin;        // index of this launch's first cluster in dbpart
   int nclusters;
   unsigned long long timeout_ticks;
+  // input gradient inside the kernel (DXK > 0): every member writes its partial dx = dgates[:, member's gate rows] . W_ih[those rows]
+  const float* Wih;    // [4H][in_dim]
+  float* dxpart;       // [NCL][clusters][T][16][in_dim] partial input gradients (a cluster's step is one contiguous block: one page
+                       // per store instead of 16), summed by dx_reduce_kernel; nullptr: not wanted
+  int ncl_total;       // clusters of the whole batch (all launches)
+  int in_dim;
+  int dx_b_begin;      // batch rows before it need no input gradient
 };
 
-template <int H, int US, int MT>
+template <int H, int US, int MT, int DXK = 0>
 __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int NCL = H / US;
   constexpr int KD = 4 * US;                       // k dimension = this member's gate rows
@@ -1025,12 +1032,19 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // dgates_t of this member as split bf16 (hi, lo): [MT*16 rows][LDG]
-  unsigned short* dgHi = reinterpret_cast<unsigned short*>(smem);
-  unsigned short* dgLo = dgHi + MT * 16 * LDG;
-  float* dhL = smem + MT * 16 * LDG;               // [MT][16][LDH] this member's partial dh_{t-1}
+  // (DXK > 0: two such tiles, by step parity -- the partial input gradient reads a step's tile in the shadow of the hand-off,
+  // with no barrier between it and the next step's gate math, which therefore writes the other one)
+  constexpr int NB = DXK > 0 ? 2 : 1;
+  constexpr int DGT = MT * 16 * LDG;               // elements of one image (hi or lo)
+  unsigned short* dg0 = reinterpret_cast<unsigned short*>(smem);
+  float* dhL = smem + NB * DGT;                    // [MT][16][LDH] this member's partial dh_{t-1}
   float* dbL = dhL + MT * 16 * LDH;                // [256][16] bias-grad reduction
   int* s_dead = reinterpret_cast<int*>(dbL + 4096);
   int* s_word = s_dead + 1;
+  // DXK > 0: W_ih^T of this member's gate rows as split bf16, [DXK input features][LDG] (k = member's gate row, contiguous):
+  // the A operand of the partial input gradient dx^T = W_ih^T . dgates^T, whose B operand is the dgates tile above
+  unsigned short* wxH = reinterpret_cast<unsigned short*>(dbL + 4096 + 4);
+  unsigned short* wxL = wxH + (DXK > 0 ? DXK : 1) * LDG;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: wave-uniform branches and addresses
   const int col = lane & 15, q = lane >> 4;
@@ -1052,6 +1066,24 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)(a.cst + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)Xc, 0, NCL > 1 ? 3 * XSLAB * 4 : 0, kBufFlags);
+  // partial input gradient of this member: rows of this cluster in dxpart[j]; clusters whose rows all lie before
+  // dx_b_begin (the real half of the discriminator's real + fake pass) skip it
+  const int xin = DXK > 0 ? a.in_dim : 0;
+  const bool dxon = DXK > 0 && a.dxpart != nullptr && b0 + vrows > a.dx_b_begin;
+  const __amdgpu_buffer_rsrc_t rDX = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(dxon ? a.dxpart + ((size_t)j * a.ncl_total + a.cl_begin + cl) * T * (MT * 16) * xin : a.X), 0,
+      dxon ? (int)((long)T * (MT * 16) * xin * 4) : 0, kBufFlags);
+  if (DXK > 0) {
+    for (int i = tid; i < DXK * KD; i += 256) {
+      const int m = i / KD, k = i % KD;
+      const int grow = (k / US) * H + j * US + (k % US);
+      const float wv = (dxon && m < xin) ? a.Wih[(long)grow * xin + m] : 0.f;
+      unsigned sh, sl;
+      tb_split2(wv, 0.f, sh, sl);
+      wxH[m * LDG + k] = (unsigned short)(sh & 0xFFFFu);
+      wxL[m * LDG + k] = (unsigned short)(sl & 0xFFFFu);
+    }
+  }
   if (NCL > 1) {
     // arm the part of the three slabs this member CONSUMES ([slab][j][every producer][rows][units], one
     // contiguous run per slab; its own never-written slot included); write-through, acknowledged before
@@ -1146,6 +1178,8 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
   STAMP_DECL;
   for (int t = T - 1; t >= 0; --t) {
     STAMP(0);
+    unsigned short* dgHi = dg0 + (NB > 1 ? (t & 1) * 2 * DGT : 0);
+    unsigned short* dgLo = dgHi + DGT;
     f32x4 nx[NQ][6];
     // prefetch step t-1 (its c_t is this step's c_{t-1}, already held), FIRST thing in the step: loads of a wave return
     // in order, so the reduce-scatter pull at the end of the step comes back no sooner than these HBM reads -- issued behind
@@ -1286,6 +1320,29 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       if (e < NE) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) stgn<UI, 0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
+      }
+    }
+    if (DXK > 0 && last) __syncthreads();   // the last step has no MFMA block and none of its barriers: the dgates tile is complete behind this one
+    if (DXK > 0 && dxon && wave < DXK / 16) {
+      // partial dx_t^T = W_ih^T[this member's gate rows] . dgates_t^T, in the shadow of the hand-off: the dgates tile stays
+      // in LDS until the next step's gate math.  Wave w: input features 16 w .. 16 w + 15; lane: batch row `col`, 4 features.
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        // three accumulators (one per term of the split product): no MFMA waits for the one before it
+        f32x4 ax0 = zero4, ax1 = zero4, ax2 = zero4;
+#pragma unroll
+        for (int s = 0; s < NKD; ++s) {
+          const int go = (mt * 16 + col) * LDG + s * 32 + q * 8, wo = (wave * 16 + col) * LDG + s * 32 + q * 8;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgHi + go));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(dgLo + go));
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wxH + wo));
+          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(wxL + wo));
+          ax0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, ax0, 0, 0, 0);
+          ax1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, ax1, 0, 0, 0);
+          ax2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, ax2, 0, 0, 0);
+        }
+        const int f0 = wave * 16 + q * 4;
+        stg4<0>(rDX, (f0 < xin && mt * 16 + col < vrows) ? ((long)t * (MT * 16) + mt * 16 + col) * xin + f0 : 0x1FFFFFFFl, (ax0 + ax1) + ax2);
       }
     }
     STAMP(5);
@@ -1506,6 +1563,26 @@ int launch_wgrad_finish(const WFinishArgs& f, hipStream_t s) {
   return TB_OK;
 }
 
+// dx[b][t][:] = sum over the members' partials part[m][b / rows][t][b % rows][:], in member order; part[m] is `stride` floats
+// behind part[m-1].  Rows of dx from r0 = (first batch row) * T on, n4 groups of 4 floats.
+__global__ void dx_reduce_kernel(const float* __restrict__ part, int nparts, long stride, long r0, long n4, int T, int in_dim,
+                                 int rows, float* __restrict__ dx) {
+  const int g4 = in_dim / 4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long r = r0 + i / g4;
+    const int f = (int)(i % g4) * 4;
+    const long b = r / T, t = r % T;
+    const size_t src = (((size_t)(b / rows) * T + t) * rows + (b % rows)) * in_dim + f;
+    f32x4 v[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) v[m] = m < nparts ? *reinterpret_cast<const f32x4*>(part + (size_t)m * stride + src) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 s = v[0];
+#pragma unroll
+    for (int m = 1; m < 8; ++m) s += v[m];
+    *reinterpret_cast<f32x4*>(dx + r * in_dim + f) = s;
+  }
+}
+
 __global__ void db_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* db_ih, float* db_hh,
                                  int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1622,15 +1699,15 @@ int launch_fwd_t(const FwdArgs& a, int grid, size_t lds, hipStream_t s) {
   return TB_OK;
 }
 
-template <int H, int US, int MT>
+template <int H, int US, int MT, int DXK = 0>
 int launch_bwd_t(const BwdArgs& a, int grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, US, MT>),
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_kernel<H, US, MT, DXK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<H, US, MT>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((lstm_bwd_kernel<H, US, MT, DXK>), dim3(grid), dim3(256), lds, s, a);
   TB_LAUNCH_CHECK("lstm_bwd_kernel");
   return TB_OK;
 }
@@ -1670,7 +1747,32 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }
 
+// The input gradient inside the BPTT kernel (DXK = 32): for clustered one-tile layers with a narrow input (in <= 32, a
+// multiple of 4: the discriminator) every member adds W_ih^T . dgates^T for its gate rows in the shadow of the hand-off and
+// writes a partial dx; dx_reduce_kernel sums the NCL partials.  It replaces the dx GEMM, i.e. one of the three passes over the
+// dgates matrix (268 - 537 MB at cfg2).  TB_DX_FUSE=0 turns it off.
+constexpr int kDXK = 32;
+bool dx_in_kernel(const Plan& p, int in_dim) {
+  static const bool on = []() { const char* e = getenv("TB_DX_FUSE"); return !e || atoi(e) != 0; }();
+  return on && p.NCL > 1 && p.NCL <= 8 && p.MT == 1 && in_dim <= kDXK && (in_dim & 3) == 0 && (p.H == 256 || p.H == 128);
+}
+size_t dx_extra_lds(const Plan& p) {   // second dgates tile + the W_ih^T tile (hi and lo)
+  const size_t ldg = 4 * p.US + 8;
+  return (size_t)p.MT * 16 * ldg * 4 + (size_t)2 * kDXK * ldg * 2 + 16;
+}
+size_t dx_part_bytes(const Plan& p, int B, int T, int in_dim) {
+  const size_t ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
+  return dx_in_kernel(p, in_dim) ? tb_align_up((size_t)p.NCL * ncl_total * p.rows_per_cluster * T * in_dim * sizeof(float), 256) : 0;
+}
+
 int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
+  if (a.dxpart) {
+    const size_t lds = p.lds_bwd + dx_extra_lds(p);
+    if (p.H == 256 && p.US == 64 && p.MT == 1) return launch_bwd_t<256, 64, 1, kDXK>(a, grid, lds, s);
+    if (p.H == 256 && p.US == 32 && p.MT == 1) return launch_bwd_t<256, 32, 1, kDXK>(a, grid, lds, s);
+    if (p.H == 128 && p.MT == 1) return launch_bwd_t<128, 32, 1, kDXK>(a, grid, lds, s);
+    return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: no in-kernel input gradient for H=%d MT=%d", p.H, p.MT);
+  }
   BWD_CASE(16, 16, 1); BWD_CASE(16, 16, 2); BWD_CASE(16, 16, 4);
   BWD_CASE(32, 32, 1); BWD_CASE(32, 32, 2); BWD_CASE(32, 32, 4);
   BWD_CASE(64, 64, 1); BWD_CASE(64, 64, 2);
@@ -1706,9 +1808,10 @@ struct Carve {
   float* dbpart;
   float* gemm_ws; size_t gemm_ws_bytes;     // two regions of gemm_ws_bytes each (backward): the two weight-gradient
   float* gemm_ws2;                          // products keep their slabs until the common finish kernel
+  float* dxpart;                            // backward, in-kernel input gradient: [NCL][B][T][in] partials (or nullptr)
 };
 
-size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c) {
+size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size_t total, Carve* c, int T = 0) {
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   size_t off = 0;
   const int ncl_launch = ncl_total < p.clusters_per_launch ? ncl_total : p.clusters_per_launch;
@@ -1717,7 +1820,6 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   // (one partial of dh per producer, reduce-scatter)
   const size_t x_bytes = p.NCL > 1 ? tb_align_up((size_t)ncl_launch * 3 * (bwd ? p.NCL : 1) * (16 * p.MT) * H * sizeof(float), 256) : 0;
   const size_t dbpart_bytes = bwd ? tb_align_up((size_t)ncl_total * 4 * H * sizeof(float), 256) : 0;
-  (void)in_dim;
   const size_t gemm_bytes = bwd ? 2 * tb_align_up(tb_gemm_ws_bytes(), 256) : 0;
   if (c) { c->hello = reinterpret_cast<unsigned long long*>(base + off); c->hello_bytes = hello_bytes; }
   off += hello_bytes;
@@ -1725,6 +1827,9 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
   off += x_bytes;
   if (c) c->dbpart = reinterpret_cast<float*>(base + off);
   off += dbpart_bytes;
+  const size_t dx_bytes = bwd ? dx_part_bytes(p, B, T, in_dim) : 0;
+  if (c) c->dxpart = dx_bytes ? reinterpret_cast<float*>(base + off) : nullptr;
+  off += dx_bytes;
   if (c) {
     c->gemm_ws = reinterpret_cast<float*>(base + off);
     c->gemm_ws_bytes = total > off ? (total - off) / 2 / 256 * 256 : 0;
@@ -1797,10 +1902,9 @@ int tb_debug_stamps(unsigned long long* out) {   // diagnostic build only
 #endif
 
 size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
-  (void)T;
   Plan p;
   if (!make_plan(H, B, p, backward == 0, in_dim)) return 0;
-  return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr);
+  return carve(p, B, H, in_dim, backward != 0, nullptr, 0, nullptr, T);
 }
 
 int tb_lstm_exclusive(int B, int in_dim, int H, int backward) {
@@ -1889,8 +1993,12 @@ static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, con
   if (!make_plan(H, B, p))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: hidden size %d not supported (16,32,64,128,256,512)", H);
   Carve c;
-  const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c);
+  const size_t need = carve(p, B, H, in_dim, true, static_cast<char*>(ws), ws_bytes, &c, T);
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
+  // input gradient inside the kernel (see dx_in_kernel): only when somebody wants it, and within the co-residency rule
+  const bool want_dx = dx && dx_row_begin < B;
+  const bool excl = p.H == 256 && p.US == 64;
+  const bool dxk = want_dx && c.dxpart && (excl || p.lds_bwd + dx_extra_lds(p) <= 80 * 1024);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: T*H too large (%d x %d)", T, H);
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
   int rc;
@@ -1910,13 +2018,21 @@ static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, con
     a.epoch = next_epoch();
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
+    a.Wih = w_ih; a.in_dim = in_dim; a.dxpart = dxk ? c.dxpart : nullptr; a.dx_b_begin = dx_row_begin; a.ncl_total = ncl_total;
     if (c0 == 0) tb_prof_begin(TB_K_LSTM_BWD, s, 4.0 * B * T * (2.0 * in_dim + 6.0 * H));
     rc = launch_bwd(p, a, ncl * p.NCL, s);
     if (rc) return rc;
   }
   tb_prof_end(TB_K_LSTM_BWD, s);
   const int M = B * T;
-  if (dx && dx_row_begin < B) {   // dx = dG . W_ih            [M,4H].[4H,in]   (first: the layer below waits for it)
+  if (dxk) {   // dx = the sum of the members' partials
+    const long r0 = (long)dx_row_begin * T, n4 = ((long)M - r0) * in_dim / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dx_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, c.dxpart, p.NCL,
+                       (long)ncl_total * p.rows_per_cluster * T * in_dim, r0, n4, T, in_dim, p.rows_per_cluster, dx);
+    TB_LAUNCH_CHECK("dx_reduce_kernel");
+  } else if (want_dx) {   // dx = dG . W_ih            [M,4H].[4H,in]   (first: the layer below waits for it)
     const long r0 = (long)dx_row_begin * T;   // only the rows whose input gradient somebody reads
     rc = tb_gemm_launch(gates + r0 * 4 * H, 4L * H, 0, w_ih, in_dim, 1, dx + r0 * in_dim, in_dim, nullptr, (int)(M - r0), in_dim,
                         4 * H, 0, 0, 1, c.gemm_ws, c.gemm_ws_bytes, s, 0);
