@@ -17,7 +17,14 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def _stream():
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(device_index=None):
+    """Raw handle of the current stream (66 look-ups per iteration: the C call is ~10x cheaper than building a
+    torch.cuda.Stream object each time)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -57,7 +64,7 @@ class Runtime:
         return rt
 
     def workspace(self, nbytes):
-        key = torch.cuda.current_stream(self.device).cuda_stream
+        key = _stream(self.device.index)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < nbytes:
             ws = self._ws[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
