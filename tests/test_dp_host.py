@@ -259,3 +259,116 @@ def test_dp2_sharding_counts_primitives_buckets(tmp_path):
     mp.spawn(_worker_units, args=(2, _free_port(), out), nprocs=2, join=True)
     ok = np.load(out)
     assert ok.all(), ok
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Worlds of 4 and 8 ranks: the halo chain over EVERY shard boundary, ragged shards, the short-slice all-gather
+# fallback, a replicated tail of fewer windows than ranks after sharded batches, and a second pass (restart_pass: the
+# adjust seed is cleared while the band history stays on rank 0) whose first batch takes the fallback.  The yardstick
+# is the single-process oracle with the same global batches (its band / adjust are pinned to the reference by
+# pipeline.npz above; adjust's seed row depends on the batch boundaries, trainer.py:209, so the fixture's batch of 32
+# cannot be reused for wider worlds).
+# ---------------------------------------------------------------------------------------------------------------
+def _worker_multi(rank, world, port, golden, out, variant, passes):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import timeband_oracle as O
+    from timeband_amd import dp, synthetic
+    from timeband_amd.dataset import WindowSet
+    from timeband_amd.metric import TIMEBANDMetric
+    from timeband_amd.postprocess import BandAdjust
+    z = np.load(golden)
+    V, To, Tf, H, L, _, N = (int(v) for v in z["meta"])
+    s = O.SeriesData(synthetic.make_series(N, V, seed=31), synthetic.time_features(N + Tf), To, Tf, split_rate=0.8)
+    _install_oracle_kernels(O, s)
+    ds = _cpu_dataset(s, passes[0][1], To, Tf)
+    pG = {k[len("ep0.train.netG."):]: z[k] for k in z.files if k.startswith("ep0.train.netG.")}
+    post = BandAdjust(ds, variant, 1.0, 0.2, 0.3, keep_outputs=True)
+    metric = TIMEBANDMetric(dict(device="cpu"))
+    res = {}
+    w0 = 0
+    for k, (nwin, B) in enumerate(passes):
+        post.restart_pass()
+        metric.init_score()
+        stamp = np.full(ds.data_length, -1, np.int64)
+        kinds = []
+        for step, data in enumerate(WindowSet(ds, w0, nwin).loader(B, rank, world)):
+            lo, n, repl = data["part"]
+            fake, _ = O.generator_fwd(pG, data["encoded"].numpy(), L)
+            idx0 = post.idx
+            reals, preds, masks, lower, upper, target = post.step(torch.from_numpy(fake[:, :Tf].astype(np.float32)),
+                                                                  data["part"])
+            first = To + idx0 + (0 if post.full_rows else lo)
+            stamp[first:first + target.shape[0]] = step
+            kinds.append((n, int(repl), int(post.full_rows), first, target.shape[0]))
+            metric.update(reals, preds, masks, full=post.full_rows)
+        res[f"p{k}.outputs"], res[f"p{k}.lower"], res[f"p{k}.upper"] = (t.numpy().copy() for t in
+                                                                       (post.outputs, post.lower_bands, post.upper_bands))
+        res[f"p{k}.stamp"], res[f"p{k}.kinds"] = stamp, np.array(kinds, dtype=np.int64)
+        res[f"p{k}.scores"] = np.array([metric.nme, metric.nmae, metric.rmse])
+        w0 += nwin
+    np.savez(f"{out}.{rank}.npz", **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,variant,passes,want_kinds", [
+    # 4 ranks: batches of 48 (slices of 12 >= Tf-1 = 11: halo over 3 boundaries), tail of 2 < 4 ranks (replicated);
+    # second pass: batches of 20 (slices of 5: all-gather fallback right after restart_pass)
+    (4, "trainer", [(242, 48), (100, 20)], [[(48, 0, 0)] * 5 + [(2, 1, 1)], [(20, 0, 1)] * 5]),
+    # 8 ranks: ragged slices of 12 / 13 (batch 100), tail of 5 < 8 ranks; then slices of 4 (fallback)
+    (8, "cleaner", [(205, 100), (64, 32)], [[(100, 0, 0)] * 2 + [(5, 1, 1)], [(32, 0, 1)] * 2]),
+    # 8 ranks: a sharded-but-short tail (13 windows over 8 ranks) after halo batches, then halo batches again
+    (8, "predictor", [(109, 96), (192, 96)], [[(96, 0, 0), (13, 0, 1)], [(96, 0, 0)] * 2]),
+])
+def test_dp_wide_worlds_halo_chain_tails_and_second_pass(tmp_path, golden_dir, world, variant, passes, want_kinds):
+    golden = os.path.join(golden_dir, "pipeline.npz")
+    out = str(tmp_path / "dpw")
+    mp.spawn(_worker_multi, args=(world, _free_port(), golden, out, variant, passes), nprocs=world, join=True)
+    rs = [np.load(f"{out}.{k}.npz") for k in range(world)]
+    sys.path.insert(0, ROOT)
+    from oracle import timeband_oracle as O
+    from timeband_amd import synthetic
+    z = np.load(golden)
+    V, To, Tf, H, L, _, N = (int(v) for v in z["meta"])
+    s = O.SeriesData(synthetic.make_series(N, V, seed=31), synthetic.time_features(N + Tf), To, Tf, 0.8)
+    pG = {k[len("ep0.train.netG."):]: z[k] for k in z.files if k.startswith("ep0.train.netG.")}
+    enc, _ = O.windowing(s.norm, s.target_cols, To, Tf)
+    pp = O.PostProcess(s, variant, 1.0, 0.2, 0.3)
+    w0 = 0
+    for k, (nwin, B) in enumerate(passes):
+        pp.restart()
+        sums = np.zeros(3)
+        for s0 in range(w0, w0 + nwin, B):
+            fake, _ = O.generator_fwd(pG, enc[s0:min(s0 + B, w0 + nwin)], L)
+            reals, preds, masks, *_ = pp.step(fake[:, :Tf])
+            sums += np.array(O.metrics(reals, preds, masks))
+        w0 += nwin
+        assert [tuple(r[:3]) for r in rs[0][f"p{k}.kinds"]] == want_kinds[k]
+        # a step that every rank runs in full leaves the SAME rows on every rank (state synchronised before it)
+        for step, (_, _, full, r0, nr) in enumerate(rs[0][f"p{k}.kinds"]):
+            if full and step == len(want_kinds[k]) - 1:
+                for r in rs[1:]:
+                    for key in ("outputs", "lower", "upper"):
+                        np.testing.assert_array_equal(r[f"p{k}.{key}"][r0:r0 + nr], rs[0][f"p{k}.{key}"][r0:r0 + nr])
+        stamps = np.stack([r[f"p{k}.stamp"] for r in rs])
+        who = stamps.argmax(0)          # a row belongs to whoever wrote it last (ties: every rank wrote the same step)
+        # the oracle's arrays restart from `observed` every pass (trainer.py:137): its row To + j is absolute row
+        # To + (first window of the pass) + j, which is where the product -- addressing rows absolutely -- wrote it
+        rows = nwin + Tf - 1
+        assert pp.outputs.shape[0] == To + rows
+        first = To + (w0 - nwin)
+        assert (stamps.max(0)[first:first + rows] >= 0).all()
+        for key, want in (("outputs", pp.outputs), ("lower", pp.lower_bands), ("upper", pp.upper_bands)):
+            got = np.stack([r[f"p{k}.{key}"] for r in rs])[who, np.arange(stamps.shape[1])]
+            # 1e-6: the numpy generator is not bit-identical across batch splits (BLAS blocking), and its output is cast
+            # to float32 -- a slice can land one float32 ulp away from the whole batch's; a wrong halo / carry is O(1)
+            np.testing.assert_allclose(got[first:first + rows], want[To:], rtol=1e-6, atol=1e-6, err_msg=f"pass {k} {key}")
+        # NME / NMAE divide by (1e-7 + real): near-zero reals make million-fold terms, so the sums carry the last-bit
+        # differences of the rows above at ~1e-8 relative; every rank must hold the SAME scores to the bit
+        for r in rs:
+            np.testing.assert_allclose(r[f"p{k}.scores"], sums, rtol=1e-6, err_msg=f"pass {k} scores")
+            np.testing.assert_array_equal(r[f"p{k}.scores"], rs[0][f"p{k}.scores"])

@@ -768,6 +768,11 @@ int tb_minmax(const double* data, long rows, int E, double* mn, double* mx, int 
     TB_LAUNCH_CHECK("minmax_partial_kernel");
     hipLaunchKernelGGL(minmax_fold_kernel, dim3((E + 63) / 64), dim3(64), 0, s, part, (int)parts, E, mn, mx, init);
     TB_LAUNCH_CHECK("minmax_fold_kernel");
+  } else if (init) {
+    // no rows to fold (int(len * split_rate) == 0): mn / mx must still be defined before the finish step reads them
+    hipLaunchKernelGGL(minmax_fold_kernel, dim3((E + 63) / 64), dim3(64), 0, s, static_cast<const double*>(nullptr), 0, E, mn,
+                       mx, 1);
+    TB_LAUNCH_CHECK("minmax_fold_kernel");
   }
   if (finish) {
     hipLaunchKernelGGL(minmax_finish_kernel, dim3((E + 63) / 64), dim3(64), 0, s, mn, mx, E);

@@ -43,6 +43,16 @@ def world() -> int:
     return dist.get_world_size()
 
 
+def ranks() -> int:
+    """Processes in the job, whatever the batch being processed is (1 if torch.distributed is not initialised; the
+    forced single-rank test mode counts as data parallel through active())."""
+    return dist.get_world_size() if initialized() else 1
+
+
+def is_replicated() -> bool:
+    return _REPLICATED
+
+
 def rank() -> int:
     return dist.get_rank() if initialized() else 0
 
@@ -262,9 +272,11 @@ class GradReducer:
         self.handles = []
         self.fired = None
 
-    def arm(self):
+    def arm(self, visits=1):
+        """visits: how often the armed backward pass reaches each parameter (1 unless a module is applied more than
+        once in the graph, e.g. LSTMDiscriminator.pair()'s two-pass fallback for unequal shapes)."""
         from . import ops
-        self.pending = [b["nparams"] for b in self.flat.buckets]
+        self.pending = [b["nparams"] * int(visits) for b in self.flat.buckets]
         self.fired = [False] * len(self.flat.buckets)
         self.handles = []
         ops._REDUCERS.append(self)
@@ -276,6 +288,12 @@ class GradReducer:
             if p is None or getattr(p, "_tb_flat", None) is not self.flat:
                 continue
             b = p._tb_bucket
+            if self.fired[b]:
+                # the bucket's all-reduce is already in flight on the communication stream and these kernels add into
+                # the slice it reads and writes: a race and a wrong sum that nothing downstream could repair
+                raise RuntimeError("dp.GradReducer: a parameter's gradient was produced again after its bucket's "
+                                   "all-reduce had been issued (a module applied more than once in the armed backward "
+                                   "pass): arm the reducer with visits=<times each parameter is reached>")
             self.pending[b] -= 1
             if self.pending[b] == 0 and not self.fired[b]:
                 self._fire(b)

@@ -13,7 +13,7 @@ from . import ops
 class TIMEBANDLoss:
     def __init__(self, config: dict):
         self.set_config(config)
-        self._running = None
+        self._running = self._running_repl = None
         self.init_loss()
 
     def set_config(self, config: dict):
@@ -23,11 +23,18 @@ class TIMEBANDLoss:
     def _run(self, device):
         if self._running is None or self._running.device != device:
             self._running = torch.zeros(8, dtype=torch.float32, device=device)
+            self._running_repl = torch.zeros(8, dtype=torch.float32, device=device)
+        # data parallel: a batch that every rank runs in full (dp.replicated(): tail batches, critic draws smaller than
+        # the world) contributes its FULL value on every rank -- kept apart from the per-rank shares, which are summed
+        # over the ranks when they are read (_sums)
+        if ops.dp.is_replicated() and ops.dp.ranks() > 1:
+            return self._running_repl
         return self._running
 
     def init_loss(self):
         if self._running is not None:
             self._running.zero_()
+            self._running_repl.zero_()
         return self.loss()
 
     def gen_loss(self, true, pred, DGx, presum=None):
@@ -56,6 +63,8 @@ class TIMEBANDLoss:
             # global means -- sum them over the ranks; l1 / l2 / gp come from globally reduced sums already
             run = run.clone()
             ops.dp.all_reduce(run[0:3])
+        if ops.dp.ranks() > 1:
+            run = run + self._running_repl
         return run.tolist()      # the one host sync, at logging time
 
     @property

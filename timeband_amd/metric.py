@@ -32,15 +32,20 @@ class TIMEBANDMetric:
         f = lambda t: torch.as_tensor(t).to(device=device, dtype=torch.float64).contiguous()
         return f(true), f(pred), torch.as_tensor(mask).to(device=device, dtype=torch.int32).contiguous()
 
-    def update(self, true, pred, mask):
+    def update(self, true, pred, mask, full=False):
         """All three scores of one batch in one launch, added to the running sums; no host sync.
         Data parallel: each rank holds the rows of its own windows; the scores are ratios of sums over ALL rows of
         the global batch, so only the five additive sums are taken here -- they are summed over the ranks and
-        turned into scores when the running values are read (one all-reduce per pass, `_flush`)."""
+        turned into scores when the running values are read (one all-reduce per pass, `_flush`).  `full`: see below."""
         dev = pred.device if torch.is_tensor(pred) and pred.is_cuda else torch.device(self.device)
         t, p, m = self._prep(true, pred, mask, dev)
         if ops.dp.active():
-            self._pending.append(ops.metric_sums(t, p, m))
+            # full: EVERY rank holds all the rows of this batch (a replicated tail batch, the all-gather fallback of the
+            # post-processing) -- they count once, from rank 0
+            sums = ops.metric_sums(t, p, m)
+            if full and ops.dp.ranks() > 1 and ops.dp.rank() != 0:
+                sums = torch.zeros_like(sums)
+            self._pending.append(sums)
             self._run(dev)
             return None
         return ops.metrics(t, p, m, self._run(dev))

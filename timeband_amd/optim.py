@@ -133,10 +133,10 @@ class _FlatOptimizer:
     # begin_reduce() BEFORE the last backward pass that adds into this network's gradients: its buckets are
     # then reduced on the communication stream as BPTT completes them; all_reduce_grads() (before step())
     # reduces what has not been and waits for all of it.
-    def begin_reduce(self):
+    def begin_reduce(self, visits=1):
         if dp.active():
             self._reducer = dp.GradReducer(self.flat)
-            self._reducer.arm()
+            self._reducer.arm(visits)
 
     def all_reduce_grads(self):
         self._join()

@@ -46,6 +46,7 @@ class BandAdjust:
         self.nhist = 0
         self.idx = 0
         self._rank0_state = False      # data parallel: after a sharded step only rank 0 holds hist / last_row
+        self.full_rows = True          # the last step's rows: all of the batch's (True) or this rank's own (sharded)
         self.restart_pass()
 
     def restart_pass(self):
@@ -62,13 +63,16 @@ class BandAdjust:
     def step(self, fake_y, part=None):
         """part (data parallel): (lo, n, replicated) -- fake_y holds windows [lo, lo + len(fake_y)) of the global
         batch of n windows that starts at self.idx (replicated: every rank holds all n)."""
-        if part is not None and dp.active() and not part[2]:
-            lo, n = int(part[0]), int(part[1])
-            Tf = fake_y.shape[1]
-            W = dp.world()
-            if min(dp.shard(n, r, W)[1] - dp.shard(n, r, W)[0] for r in range(W)) >= Tf - 1:
-                return self._step_shard(fake_y, lo, n)
-            fake_y = dp.all_gather_cat(fake_y.detach().contiguous())     # short slices: the whole batch everywhere
+        if part is not None and (dp.ranks() > 1 or dp.active()):
+            if not part[2]:
+                lo, n = int(part[0]), int(part[1])
+                Tf = fake_y.shape[1]
+                W = dp.ranks()
+                if min(dp.shard(n, r, W)[1] - dp.shard(n, r, W)[0] for r in range(W)) >= Tf - 1:
+                    return self._step_shard(fake_y, lo, n)
+                fake_y = dp.all_gather_cat(fake_y.detach().contiguous())     # short slices: the whole batch everywhere
+            # a step that every rank runs in full (the all-gather fallback above, or a replicated tail batch with
+            # fewer windows than ranks): everybody needs the state that sharded steps left on rank 0 only
             self._sync_state()
         return self._step_all(fake_y)
 
@@ -80,13 +84,17 @@ class BandAdjust:
         d = self.ds
         dp.broadcast(self.hist[self.cur], 0)
         self.nhist = d.forecast_len - 1
-        if self.last_row is None:
-            self.last_row = torch.empty(d.decode_dim, dtype=torch.float64, device=self.hist[0].device)
-        self.last_row = dp.broadcast(self.last_row.contiguous(), 0)
+        # `last_row is None` means "seed = the last observed row" (trainer.py:137,209; restart_pass clears it on every
+        # rank at the top of a pass while the band history stays on rank 0): rank 0 sends that row itself, so what
+        # the others receive is always a defined seed
+        row = d.observed_dev[-1] if self.last_row is None else self.last_row
+        row = row.to(torch.float64).clone().contiguous()
+        self.last_row = dp.broadcast(row, 0)
         self._rank0_state = False
 
     def _step_all(self, fake_y):
         d = self.ds
+        self.full_rows = True
         B, Tf, V = fake_y.shape
         # the history holds normalised predictions: the band kernel denormalises as it gathers
         preds, lower, upper = ops.band_update(fake_y.detach(), self.hist[self.cur], self.nhist, self.hist[self.cur ^ 1],
@@ -153,4 +161,5 @@ class BandAdjust:
         self._keep(first, target, lower, upper)
         self.idx += n
         self._rank0_state = W > 1
+        self.full_rows = False
         return reals, preds, masks, lower, upper, target

@@ -240,6 +240,9 @@ class TIMEBANDTrainer:
                     fake_y = netG(true_x)
                 if dphase is not None:
                     s1.wait_event(dphase[2])
+                    # fake_y.grad was allocated on the main stream and its last reference goes two lines down: without
+                    # this the block returns to the main stream's pool while s1's backward kernels still read it
+                    dphase[1].record_stream(s1)
                     with torch.cuda.stream(s1):
                         dphase[0].backward(dphase[1])
                     dphase = None
@@ -312,11 +315,12 @@ class TIMEBANDTrainer:
             else:
                 fake_y = self.iteration(true_x, true_y, training, n_global=None if part is None else part[1])
             reals, preds, masks, lower, upper, target = self.post.step(fake_y, part)
+            full_rows = self.post.full_rows      # every rank holds ALL rows of this batch: only rank 0's sums count
             self.idx = self.post.idx
             if self.dashboard is not None and getattr(self.dashboard, "vis_opt", False):
                 self.dashboard.vis(true_y.shape[0], reals.cpu().numpy(), preds.cpu().numpy(), lower.cpu().numpy(),
                                    upper.cpu().numpy(), target.cpu().numpy())
-            self.metric.update(reals, preds, masks)
+            self.metric.update(reals, preds, masks, full=full_rows)
         if i < 0:
             return float("nan")
         ops.check_errors(dev)
