@@ -194,6 +194,131 @@ def run_scenario(name, V, E, To, Tf, H, L, B, lr=2e-4):
 
 
 # --------------------------------------------------------------------------------------
+# Hidden 256 (the clustered kernels' sizes): cfg2's shape and model.cfg's observed 10 / forecast 3.
+# Stored compactly so each file stays near 1 MB: the inputs are NOT stored -- the test regenerates them
+# with the same seed and torch.rand calls (init is bit-identical by seed) and checks the checksums kept
+# here; tensors above 16384 elements are kept as a seeded sample of 4096 entries (`sample_index`).
+# --------------------------------------------------------------------------------------
+BIG = {
+    "h256": dict(V=32, E=36, To=128, Tf=128, H=256, L=1, B=4),        # BASELINE.json configs[1] shape
+    "uneven_h256": dict(V=3, E=5, To=10, Tf=3, H=256, L=1, B=5),      # model.cfg: observed 10, forecast 3, hidden 256
+}
+SAMPLE_ABOVE, SAMPLE_N, SAMPLE_SEED = 16384, 4096, 1234
+
+
+def sample_index(numel):
+    return np.sort(np.random.default_rng(SAMPLE_SEED + numel % 9973).choice(numel, SAMPLE_N, replace=False))
+
+
+def pack(a):
+    a = np.asarray(a)
+    return a.copy() if a.size <= SAMPLE_ABOVE else a.reshape(-1)[sample_index(a.size)].copy()
+
+
+def checksum(a):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a.sum(), (a * a).sum(), (a * np.arange(1, a.size + 1) % 7).sum()])
+
+
+def big_inputs(V, E, To, Tf, B):
+    """The scenario's inputs, drawn right after the networks were built (same calls, same order, in the test)."""
+    x = torch.rand(B, To, E) * 2 - 1
+    y = torch.rand(B, Tf, V) * 2 - 1
+    xc = torch.rand(Tf, To, E) * 2 - 1
+    yc = torch.rand(Tf, Tf, V) * 2 - 1
+    return x, y, xc, yc
+
+
+def run_scenario_big(name, V, E, To, Tf, H, L, B, lr=2e-4):
+    dev = torch.device("cpu")
+    seeding(31)
+    netD = LSTMDiscriminator(V, H, L, dev)
+    netG = LSTMGenerator(E, V, To, Tf, H, L, dev)
+    out = {}
+    for pre, net in (("init.netD", netD), ("init.netG", netG)):
+        for k, v in net.state_dict().items():
+            out[f"{pre}.{k}.checksum"] = checksum(v.numpy())
+    x, y, xc, yc = big_inputs(V, E, To, Tf, B)
+    for k, v in (("x", x), ("y", y), ("xc", xc), ("yc", yc)):
+        out[f"{k}.checksum"] = checksum(v.numpy())
+    with torch.no_grad():
+        Gx = netG(x)
+        out["fwd.Gx"] = Gx.numpy().copy()
+        out["fwd.Dy"] = netD(y).numpy().copy()
+        out["fwd.DGx"] = netD(Gx).numpy().copy()
+        losses = make_losses()
+        Dy_t, DGx_t = torch.tensor(out["fwd.Dy"]), torch.tensor(out["fwd.DGx"])
+        out["loss.dis"] = np.float32(losses.dis_loss(y, Gx, Dy_t, DGx_t).item())
+        out["loss.dis_critic"] = np.float32(losses.dis_loss(y, Gx, Dy_t, DGx_t, critic=True).item())
+        out["loss.gen"] = np.float32(losses.gen_loss(y, Gx, DGx_t).item())
+        out["loss.gan_fake"] = np.float32(losses.GANloss(DGx_t, False).item())
+        out["loss.gan_real"] = np.float32(losses.GANloss(Dy_t, True).item())
+        out["loss.l1"] = np.float32(losses.l1loss(y, Gx).item())
+        out["loss.l2"] = np.float32(losses.l2loss(y, Gx).item())
+        out["loss.gp"] = np.float32(losses.grad_penalty(y, Gx).item())
+    # one iteration exactly as trainer.py:142-194 (critic=1)
+    losses = make_losses()
+    adamD, adamG = Adam(netD.parameters(), lr=lr), Adam(netG.parameters(), lr=lr)
+
+    def keep_grads(net, tag):
+        for k, p_ in net.named_parameters():
+            out[f"{tag}.{k}"] = pack(p_.grad.detach().numpy())
+            out[f"{tag}.{k}.absmax"] = np.float64(p_.grad.detach().abs().max().item())
+
+    def keep_params(net, tag):
+        for k, v in net.state_dict().items():
+            out[f"{tag}.{k}"] = pack(v.numpy())
+
+    # The WGAN critic's gradients are residues of two cancelling sums (-mean D(real) + mean D(fake), loss.py:107-112;
+    # e.g. the LSTM bias: 1.1e-2 - 1.1e-2 -> 4e-4): the scale an fp32 implementation can be held to is the size of
+    # the PARTS.  Their largest entries per tensor are recorded for the tolerance (two extra backward passes of the
+    # reference's own modules; no parameter is touched).
+    with torch.no_grad():
+        fake0 = netG(xc)
+    parts = []
+    for term in (lambda: -netD(yc).mean(), lambda: netD(fake0).mean()):
+        netD.zero_grad()
+        term().backward()
+        parts.append({k: p_.grad.detach().abs().max().item() for k, p_ in netD.named_parameters()})
+    netD.zero_grad()
+    for k in parts[0]:
+        out[f"it0.critic.grad.netD.{k}.partmax"] = np.float64(max(parts[0][k], parts[1][k]))
+    optimD = RMSprop(netD.parameters(), lr=lr)
+    fake = netG(xc)
+    optimD.zero_grad()
+    errD = losses.dis_loss(yc, fake, netD(yc), netD(fake), critic=True)
+    errD.backward()
+    out["it0.critic.errD"] = np.float32(errD.item())
+    keep_grads(netD, "it0.critic.grad.netD")
+    optimD.step()
+    keep_params(netD, "it0.critic.after.netD")
+    adamD.zero_grad()
+    adamG.zero_grad()
+    fake = netG(x)
+    errD = losses.dis_loss(y, fake, netD(y), netD(fake))
+    errD.backward()
+    out["it0.dphase.errD"] = np.float32(errD.item())
+    keep_grads(netD, "it0.dphase.grad.netD")
+    keep_grads(netG, "it0.dphase.grad.netG")
+    adamD.step()
+    keep_params(netD, "it0.dphase.after.netD")
+    fake = netG(x)
+    errG = losses.gen_loss(y, fake, netD(fake))
+    errG.backward()
+    out["it0.gphase.errG"] = np.float32(errG.item())
+    keep_grads(netG, "it0.gphase.grad.netG")
+    adamG.step()
+    keep_params(netG, "it0.gphase.after.netG")
+    out["it0.fake_y"] = fake.detach().numpy().copy()
+    out["meta"] = np.array([V, E, To, Tf, H, L, B], dtype=np.int64)
+    out["lr"] = np.float64(lr)
+    out["sampling"] = np.array([SAMPLE_ABOVE, SAMPLE_N, SAMPLE_SEED], dtype=np.int64)
+    path = os.path.join(HERE, f"scenario_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"scenario_{name}.npz: {len(out)} arrays, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+# --------------------------------------------------------------------------------------
 # G6: band (predicts) and adjust, straight from the three reference classes
 # --------------------------------------------------------------------------------------
 class _DS:
@@ -401,6 +526,12 @@ def run_pipeline():
 
 
 if __name__ == "__main__":
+    if "h256" in sys.argv[1:]:          # only the hidden-256 scenarios (the other files stay as committed)
+        for nm, sc in BIG.items():
+            run_scenario_big(nm, **sc)
+        sys.exit(0)
+    for nm, sc in BIG.items():
+        run_scenario_big(nm, **sc)
     for nm, sc in SCENARIOS.items():
         run_scenario(nm, **sc)
     run_band_adjust()

@@ -357,3 +357,42 @@ def test_genb_band_and_adjust(golden_dir):
         n = B + Tf - 1
         got = O.adjust("genb", z[f"band.{k}.output"].copy(), med, z["band.miss"][k * B:k * B + n], lo, up, a, b)
         np.testing.assert_allclose(got, z[f"band.{k}.target"], rtol=1e-13, atol=1e-13)
+
+
+# --------------------------------------------------------------------------------------------------
+# Hidden 256: cfg2's shape (32 variables, window 128) and model.cfg's observed 10 / forecast 3 -- the sizes at which
+# the HIP path runs its clustered kernels -- against a run of the reference (tests/h256_util.py).
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["h256", "uneven_h256"])
+def test_h256_reference_scenarios(name):
+    import h256_util as U
+    z = U.load(name)
+    netD, netG, x, y, xc, yc = U.regenerate(z)
+    V, E, To, Tf, H, L, B = (int(v) for v in z["meta"])
+    pD = {k: v.numpy().copy() for k, v in netD.state_dict().items()}
+    pG = {k: v.numpy().copy() for k, v in netG.state_dict().items()}
+    x, y, xc, yc = (t.numpy() for t in (x, y, xc, yc))
+    Gx, _ = O.generator_fwd(pG, x, L)
+    Dy, _ = O.discriminator_fwd(pD, y, L)
+    DGx, _ = O.discriminator_fwd(pD, Gx, L)
+    assert relerr(Gx, z["fwd.Gx"]) < 1e-5 and relerr(Dy, z["fwd.Dy"]) < 1e-5 and relerr(DGx, z["fwd.DGx"]) < 1e-5
+    Ls = O.Losses(50, 50, 50)
+    assert relerr(Ls.dis_loss(y, Gx, Dy, DGx)[0], z["loss.dis"]) < 1e-5
+    assert relerr(Ls.dis_loss(y, Gx, Dy, DGx, critic=True)[0], z["loss.dis_critic"]) < 1e-5
+    assert relerr(Ls.gen_loss(y, Gx, DGx)[0], z["loss.gen"]) < 1e-5
+    l1, l2, gp, _, _ = O.recon_terms(y, Gx, 50, 50, 50)
+    assert relerr(l1, z["loss.l1"]) < 1e-5 and relerr(l2, z["loss.l2"]) < 1e-5 and relerr(gp, z["loss.gp"]) < 1e-5
+    lr = float(z["lr"])
+    st = O.TrainState(pD, pG, n_layers=L, lr=lr)
+    rec = {}
+    fake = O.train_iteration(st, x, y, xc, yc, rec=rec)
+    assert relerr(rec["critic.errD"], z["it0.critic.errD"]) < 1e-5
+    assert relerr(rec["dphase.errD"], z["it0.dphase.errD"]) < 1e-5
+    assert relerr(rec["gphase.errG"], z["it0.gphase.errG"]) < 1e-5
+    assert relerr(fake, z["it0.fake_y"]) < 1e-5
+    U.grads_close(rec["critic.grad.netD"], z, "it0.critic.grad.netD", 1e-3)
+    U.grads_close(rec["dphase.grad.netD"], z, "it0.dphase.grad.netD", 1e-3)
+    U.grads_close(rec["dphase.grad.netG"], z, "it0.dphase.grad.netG", 1e-3)
+    U.grads_close(rec["gphase.grad.netG"], z, "it0.gphase.grad.netG", 1e-3)
+    U.params_close(st.pD, z, "it0.dphase.after.netD", lr)
+    U.params_close(st.pG, z, "it0.gphase.after.netG", lr)
