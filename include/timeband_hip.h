@@ -157,6 +157,14 @@ int tb_adam_step(float* p, const float* g, float* m, float* v, long n, double lr
 int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, double alpha, double eps, int fresh,
                     void* stream);
 
+/* Gradient-buffer housekeeping on the caller's stream (no counterpart in the reference's source: these are what
+ * torch does inside optimizer.zero_grad() / autograd's accumulation, source/trainer.py:151,160-161,179,193, and
+ * torch.cat).  tb_zero: bytes <- 0.  tb_grad_merge: g[i] += g2[i]; g2[i] = 0 (two backward passes of one network that
+ * ran side by side into two buffers; 16-byte aligned).  tb_concat2: out = a followed by b (device-to-device copies). */
+int tb_zero(void* p, size_t bytes, void* stream);
+int tb_grad_merge(float* g, float* g2, long n, void* stream);
+int tb_concat2(const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* out, void* stream);
+
 /* ---- data side ------------------------------------------------------------------------------------
  * tb_window_gather: windows of the normalised series (source/dataset.py:199-214 + utils/dataset.py:17-23):
  *   window w starts at row i = starts ? starts[w] : first + w*stride;

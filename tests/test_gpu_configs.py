@@ -367,17 +367,19 @@ def test_full_size_gradients_add_over_the_batch(dev, cfg2_nets):
         n.zero_grad(set_to_none=True)
 
 
-def test_overlapped_iteration_equals_single_stream(dev):
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_overlapped_iteration_equals_single_stream(dev, hidden):
     """TIMEBANDTrainer.iteration with the generator work on side streams (default, and each part of it
-    alone: TB_OVERLAP bit mask) and on one stream (TB_OVERLAP=0) leave bit-identical parameters after
+    alone: TB_OVERLAP bit mask), with and without the two generator forward passes computed as one 2B-row pass
+    (bit 16, LSTMGenerator.twin), and on one stream (TB_OVERLAP=0) leave bit-identical parameters after
     two iterations."""
     import bench
-    cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
+    cfg = dict(V=8, NT=4, To=24, Tf=24, H=hidden, L=1, B=96, N=3000)
     results = []
-    for mask in (5, 0, 1, 2, 4, 7, 13, 15):
+    for mask in ((21, 0, 16, 1, 2, 4, 5, 7, 13, 15, 17, 20, 29, 31) if hidden == 128 else (21, 0, 5, 16, 29)):
         np.random.seed(3)
         ds, trainset, trainer = bench.build(cfg, dev)
-        trainer.overlap, trainer.overlap_mask = mask != 0, mask
+        trainer.overlap_mask = mask
         for i in range(2):
             b = trainset.gather(i * cfg["B"], cfg["B"])
             trainer.iteration(b["encoded"], b["decoded"], training=True)

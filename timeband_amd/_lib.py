@@ -58,6 +58,9 @@ SIGNATURES = {
     "tb_recon_loss_grad": (I, [P, P, L, D, D, P, F, F, F, P, P, I, P]),
     "tb_adam_step": (I, [P, P, P, P, L, D, D, D, D, I, P]),
     "tb_rmsprop_step": (I, [P, P, P, L, D, D, D, I, P]),
+    "tb_zero": (I, [P, Z, P]),
+    "tb_grad_merge": (I, [P, P, L, P]),
+    "tb_concat2": (I, [P, Z, P, Z, P, P]),
     "tb_interpolate_workspace_bytes": (Z, [L, I]),
     "tb_interpolate": (I, [P, L, I, P, I, L, P, P, Z, P]),
     "tb_minmax_workspace_bytes": (Z, [I]),

@@ -456,7 +456,51 @@ int tb_linear_finish(const TbGemmDeferred* d, const double* part, int nparts, in
   return TB_OK;
 }
 
+namespace {
+// grad += grad2; grad2 = 0  (16 bytes per lane; the tail element-wise)
+__global__ void grad_merge_kernel(float* __restrict__ g, float* __restrict__ g2, long n) {
+  const long n4 = n / 4;
+  f32x4* a = reinterpret_cast<f32x4*>(g);
+  f32x4* b = reinterpret_cast<f32x4*>(g2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    a[i] = a[i] + b[i];
+    b[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    g[i] += g2[i];
+    g2[i] = 0.f;
+  }
+}
+}  // namespace
+
 extern "C" {
+
+int tb_zero(void* p, size_t bytes, void* stream) {
+  if (!bytes) return TB_OK;
+  if (!p) return tb_set_error(TB_ERR_ARG, "zero: null pointer");
+  return tb_check_hip(hipMemsetAsync(p, 0, bytes, static_cast<hipStream_t>(stream)), "zero");
+}
+
+int tb_grad_merge(float* g, float* g2, long n, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n <= 0) return TB_OK;
+  if (!g || !g2 || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(g2)) & 15))
+    return tb_set_error(TB_ERR_ARG, "grad_merge: null or unaligned pointer");
+  hipLaunchKernelGGL(grad_merge_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, g, g2, n);
+  TB_LAUNCH_CHECK("grad_merge_kernel");
+  return TB_OK;
+}
+
+int tb_concat2(const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if ((bytes_a && !a) || (bytes_b && !b) || ((bytes_a || bytes_b) && !out)) return tb_set_error(TB_ERR_ARG, "concat2: null pointer");
+  if (bytes_a) {
+    int rc = tb_check_hip(hipMemcpyAsync(out, a, bytes_a, hipMemcpyDeviceToDevice, s), "concat2");
+    if (rc) return rc;
+  }
+  if (bytes_b) return tb_check_hip(hipMemcpyAsync(static_cast<char*>(out) + bytes_a, b, bytes_b, hipMemcpyDeviceToDevice, s), "concat2");
+  return TB_OK;
+}
 
 int tb_adam_step(float* p, const float* g, float* m, float* v, long n, double lr, double b1, double b2,
                  double eps, int step, void* stream) {

@@ -171,34 +171,59 @@ def grads_enqueued(slots, params):
 # ----------------------------------------------------------------------------------------------
 # LSTM layer
 # ----------------------------------------------------------------------------------------------
+def lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train, split=0):
+    """One LSTM layer forward, no autograd: (y (B,T,H), gates (B,T,4H), cst (B,T,H) or None).  split > 0: the batch is
+    launched in pieces of `split` rows (rows are independent: the same bits whichever way the batch is cut -- it keeps a
+    hidden-256 layer of more than 512 rows on the 8-member cluster layout, which may share the chip with another
+    clustered launch, instead of the exclusive 4-member one)."""
+    x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
+    B, T, In = x.shape
+    H = w_hh.shape[1]
+    if w_ih.shape != (4 * H, In) or w_hh.shape != (4 * H, H):
+        raise RuntimeError("lstm: weight shapes do not match the input")
+    lib = _lib.load()
+    if not lib.tb_lstm_supported(H):
+        raise RuntimeError(f"lstm: hidden size {H} is not supported by the HIP kernels "
+                           "(supported: 16, 32, 64, 128, 256, 512)")
+    rt = Runtime.get(x.device)
+    y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
+    gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=x.device)
+    cst = torch.empty(B, T, H, dtype=torch.float32, device=x.device) if train else None
+    step = B if split <= 0 else min(int(split), B)
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        nws = lib.tb_lstm_workspace_bytes(nb, T, In, H, 0)
+        ws = rt.workspace(nws)
+        excl = H > 64 and bool(lib.tb_lstm_exclusive(nb, In, H, 0))
+        if H > 64:
+            rt.clustered_begin(excl)
+        _lib.call("tb_lstm_fwd", x.data_ptr() + 4 * b0 * T * In, _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh),
+                  y.data_ptr() + 4 * b0 * T * H, gates.data_ptr() + 16 * b0 * T * H,
+                  0 if cst is None else cst.data_ptr() + 4 * b0 * T * H, nb, T, In, H, int(train), _ptr(ws), ws.numel(),
+                  _ptr(rt.err), _stream())
+        if H > 64:
+            rt.clustered_end(excl)
+    return y, gates, cst
+
+
 class _LSTMLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train, dx_from=0):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train, dx_from=0, pre=None):
+        # pre = (y, gates, cst): this layer's forward was already computed (LSTMGenerator.twin: one pass over the
+        # rows of two forward passes) -- only the graph node is made here, around those buffers
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh)
         ctx.params = (w_ih, w_hh, b_ih, b_hh)
         ctx.dx_from = int(dx_from)
-        x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
+        x, w_ih, w_hh = (_f32c(t) for t in (x, w_ih, w_hh))
         B, T, In = x.shape
         H = w_hh.shape[1]
-        if w_ih.shape != (4 * H, In) or w_hh.shape != (4 * H, H):
-            raise RuntimeError("lstm: weight shapes do not match the input")
-        lib = _lib.load()
-        if not lib.tb_lstm_supported(H):
-            raise RuntimeError(f"lstm: hidden size {H} is not supported by the HIP kernels "
-                               "(supported: 16, 32, 64, 128, 256, 512)")
-        rt = Runtime.get(x.device)
-        y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
-        gates = torch.empty(B, T, 4 * H, dtype=torch.float32, device=x.device)
-        cst = torch.empty(B, T, H, dtype=torch.float32, device=x.device) if train else None
-        nws = lib.tb_lstm_workspace_bytes(B, T, In, H, 0)
-        ws = rt.workspace(nws)
-        excl = H > 64 and bool(lib.tb_lstm_exclusive(B, In, H, 0))
-        if H > 64:
-            rt.clustered_begin(excl)
-        _lib.call("tb_lstm_fwd", _ptr(x), _ptr(w_ih), _ptr(w_hh), _ptr(b_ih), _ptr(b_hh), _ptr(y), _ptr(gates),
-                  _ptr(cst), B, T, In, H, int(train), _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
-        if H > 64:
-            rt.clustered_end(excl)
+        if pre is None:
+            y, gates, cst = lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train)
+        else:
+            y, gates, cst = pre
+            if y.shape != (B, T, H) or gates.shape != (B, T, 4 * H) or not (y.is_contiguous() and gates.is_contiguous()):
+                raise RuntimeError("lstm: precomputed buffers do not match the input")
+            y = y.view_as(y)        # a tensor of its own for autograd (same memory)
         if train:
             ctx.save_for_backward(x, w_ih, w_hh, y, gates, cst)
             ctx.dims = (B, T, In, H)
@@ -252,47 +277,81 @@ class _LSTMLayerFn(torch.autograd.Function):
                     t.record_stream(wg)
                 rt._wg_dirty = True
                 grads_enqueued(slots, ctx.params)      # an armed reducer records its event on THIS stream
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         if slots is not None:
             grads_enqueued(slots, ctx.params)
-            return dx, None, None, None, None, None, None
-        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None, None
 
 
-def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0):
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0, pre=None):
     """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H).  dx_from: the caller promises that nobody reads
-    the input gradient of the batch rows [0, dx_from) -- it is then not computed (those rows of x.grad are garbage)."""
+    the input gradient of the batch rows [0, dx_from) -- it is then not computed (those rows of x.grad are garbage).
+    pre: see _LSTMLayerFn.forward."""
     # grad mode is off inside Function.forward, so the stash decision is taken here
     train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh)))
-    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from)
+    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from, pre)
 
 
-def lstm_stack(x, lstm_module, dx_from=0):
+import os as _os
+_TWIN_SPLIT = _os.environ.get("TB_TWIN_SPLIT", "1") != "0"     # experiment knob: 0 = hidden-256 twin layers as ONE (exclusive) launch
+
+
+def _lstm_params(lstm_module, l):
+    return (getattr(lstm_module, f"weight_ih_l{l}"), getattr(lstm_module, f"weight_hh_l{l}"),
+            getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"))
+
+
+def lstm_stack(x, lstm_module, dx_from=0, pre=None):
     """Run x through the layers of a torch.nn.LSTM parameter container with the HIP kernels (dx_from: see lstm_layer;
-    it applies to the first layer, whose input is x)."""
+    it applies to the first layer, whose input is x).  pre: one (y, gates, cst) per layer, see _LSTMLayerFn.forward."""
     for l in range(lstm_module.num_layers):
-        x = lstm_layer(x, getattr(lstm_module, f"weight_ih_l{l}"), getattr(lstm_module, f"weight_hh_l{l}"),
-                       getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"),
-                       dx_from if l == 0 else 0)
+        x = lstm_layer(x, *_lstm_params(lstm_module, l), dx_from if l == 0 else 0, None if pre is None else pre[l])
     return x
+
+
+def lstm_stack_raw(x, lstm_module, split=0):
+    """lstm_stack without autograd, keeping the BPTT stash: (output, [(y, gates, cst) per layer])."""
+    out = []
+    for l in range(lstm_module.num_layers):
+        y, gates, cst = lstm_fwd_raw(x, *(p.detach() for p in _lstm_params(lstm_module, l)), True,
+                                     split if (lstm_module.hidden_size >= 256 and _TWIN_SPLIT) else 0)
+        out.append((y, gates, cst))
+        x = y
+    return x, out
 
 
 # ----------------------------------------------------------------------------------------------
 # Linear (+ activation)
 # ----------------------------------------------------------------------------------------------
+def linear_act_raw(x, W, b, act):
+    """act(x @ W.T + b) for a 2-D x, no autograd (GEMM tiles; any output width)."""
+    x, W = _f32c(x), _f32c(W)
+    b = _f32c(b) if b is not None else None
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise RuntimeError("linear: weight shape does not match the input")
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _lib.call("tb_linear_act_fwd", _ptr(x), _ptr(W), _ptr(b), _ptr(y), M, K, N, act, _stream())
+    return y
+
+
 class _LinearActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, act):
+    def forward(ctx, x, W, b, act, pre=None):
+        # pre: the output, already computed (LSTMGenerator.twin); only the graph node is made here
         _need_cuda(x, W, b)
         ctx.params = (W, b)
         x, W = _f32c(x), _f32c(W)
-        b = _f32c(b) if b is not None else None
         M, K = x.shape
         N = W.shape[0]
-        if W.shape[1] != K:
-            raise RuntimeError("linear: weight shape does not match the input")
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        _lib.call("tb_linear_act_fwd", _ptr(x), _ptr(W), _ptr(b), _ptr(y), M, K, N, act, _stream())
+        if pre is None:
+            y = linear_act_raw(x, W, b, act)
+        else:
+            if pre.shape != (M, N) or not pre.is_contiguous():
+                raise RuntimeError("linear: precomputed output does not match the input")
+            y = pre.view_as(pre)
         ctx.save_for_backward(x, W, y if act else None)
         ctx.act = act
         ctx.has_b = b is not None
@@ -325,8 +384,8 @@ class _LinearActFn(torch.autograd.Function):
                   1 if slots is not None else 0, _ptr(ws), ws.numel(), _stream())
         if slots is not None:
             grads_enqueued(slots, ctx.params)
-            return dx, None, None, None
-        return dx, dW, db, None
+            return dx, None, None, None, None
+        return dx, dW, db, None, None
 
 
 class _HeadFn(torch.autograd.Function):
@@ -374,12 +433,12 @@ def _aligned16(*ts):
     return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
 
 
-def linear_act(x2d, W, b, act=ACT_NONE):
-    """act(x2d @ W.T + b) for a 2-D x."""
-    if W.shape[0] == 1 and _lib.load().tb_head_supported(W.shape[1]) and x2d.is_contiguous() and W.is_contiguous() \
-            and _aligned16(x2d, W):
+def linear_act(x2d, W, b, act=ACT_NONE, pre=None):
+    """act(x2d @ W.T + b) for a 2-D x.  pre: see _LinearActFn.forward."""
+    if pre is None and W.shape[0] == 1 and _lib.load().tb_head_supported(W.shape[1]) and x2d.is_contiguous() \
+            and W.is_contiguous() and _aligned16(x2d, W):
         return _HeadFn.apply(x2d, W, b, act)
-    return _LinearActFn.apply(x2d, W, b, act)
+    return _LinearActFn.apply(x2d, W, b, act, pre)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -744,6 +803,49 @@ def metric_finish(sums, running=None):
     out = torch.empty(k, 3, dtype=torch.float64, device=sums.device)
     _lib.call("tb_metric_finish", _ptr(sums), k, _ptr(out), _ptr(running), _stream())
     return out
+
+
+def zero_(t):
+    """t <- 0 on the current stream (contiguous tensor)."""
+    if not t.is_contiguous():
+        raise RuntimeError("zero_: contiguous tensors only")
+    _lib.call("tb_zero", _ptr(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def grad_merge(g, g2):
+    """g += g2; g2 <- 0 (flat float32 buffers)."""
+    _lib.call("tb_grad_merge", _ptr(g), _ptr(g2), g.numel(), _stream())
+
+
+def concat2(a, b):
+    """torch.cat([a, b], 0) for contiguous tensors of the same trailing shape, as two device copies."""
+    _need_cuda(a, b)
+    if a.shape[1:] != b.shape[1:] or a.dtype != b.dtype or not (a.is_contiguous() and b.is_contiguous()):
+        raise RuntimeError("concat2: contiguous tensors of the same dtype and trailing shape")
+    out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    _lib.call("tb_concat2", _ptr(a), a.numel() * a.element_size(), _ptr(b), b.numel() * b.element_size(), _ptr(out),
+              _stream())
+    return out
+
+
+class _Concat2Fn(torch.autograd.Function):
+    """concat2 with the gradient handed back as the two halves (views: no kernel)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.na = a.shape[0]
+        return concat2(a.detach(), b.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g[:ctx.na] if ctx.needs_input_grad[0] else None), (g[ctx.na:] if ctx.needs_input_grad[1] else None)
+
+
+def cat2(a, b):
+    if a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:]:
+        return _Concat2Fn.apply(a, b)
+    return torch.cat([a, b], 0)
 
 
 def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8):

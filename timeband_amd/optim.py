@@ -89,8 +89,7 @@ class FlatParams:
 
     def merge_alt(self):
         if getattr(self, "grad2", None) is not None:
-            self.grad.add_(self.grad2)
-            self.grad2.zero_()
+            ops.grad_merge(self.grad, self.grad2)
 
     def check(self):
         """Parameters / grads must still alias the flat buffers (e.g. nobody set .grad = None)."""
@@ -127,7 +126,7 @@ class _FlatOptimizer:
     def zero_grad(self, set_to_none: bool = False):
         self.flat.check()
         self._join()
-        self.flat.grad.zero_()
+        ops.zero_(self.flat.grad)
 
     # Data parallel: sum all-reduce of the gradient buffer (the loss kernels already divide by GLOBAL counts).
     # begin_reduce() BEFORE the last backward pass that adds into this network's gradients: its buckets are

@@ -45,9 +45,13 @@ class TIMEBANDTrainer:
         # leave most of the chip idle).  TB_OVERLAP is a bit mask (see iteration()); 0 = one stream.
         # Default 5: putting the G-phase forward under the D-phase backward as well (bit 2) measured
         # 1.4 % slower -- the two stretch each other by more than the forward takes.
-        ov = os.environ.get("TB_OVERLAP", "5")
-        self.overlap_mask = int(ov) if ov.isdigit() else 5
-        self.overlap = self.overlap_mask != 0
+        # Bit 16 (on by default, any number of streams): the two generator forward passes of an iteration -- the same
+        # input through the same parameters, trainer.py:173,188 -- as ONE pass over 2B rows (LSTMGenerator.twin).
+        # Bit 8 with it (default since the twin pass: 6.84 -> 6.75 ms/step): the generator phase is short now, so the
+        # D-phase generator backward is still running when the G-phase one could start.
+        ov = os.environ.get("TB_OVERLAP", "29")
+        self.overlap_mask = int(ov) if ov.isdigit() else 29
+        self.overlap = (self.overlap_mask & 15) != 0
         # TB_SHARE_GPASS=1 (off by default; not the reference's schedule): G's parameters are the same in
         # the D phase and the G phase, so netG(true_x) is the same tensor both times and backward is linear
         # in the upstream gradient -- one generator forward and ONE backward with the summed gradient give
@@ -151,7 +155,7 @@ class TIMEBANDTrainer:
         draws from dataset.get_random()).  Data parallel: true_x / true_y are this rank's slice of a global
         batch of `n_global` windows (default: equal slices on every rank).  Returns the G-phase fake_y."""
         netD, netG = self.models.netD, self.models.netG
-        overlap = self.overlap and training and true_x.is_cuda
+        overlap = (self.overlap_mask & 15) != 0 and training and true_x.is_cuda
         ops.Runtime.wgrad_overlap = bool(self.wgrad_overlap and training and true_x.is_cuda)
         # which parts overlap (TB_OVERLAP bit mask, default 5): 1 = D-phase generator forward under the
         # critic step, 2 = G-phase generator forward under the D-phase backward, 4 = graph cut at fake_y
@@ -162,8 +166,10 @@ class TIMEBANDTrainer:
         ov1, ov2, ov4, ov8 = ((overlap and bool(self.overlap_mask & b)) for b in (1, 2, 4, 8))
         ov8 = ov8 and ov4
         share = self.share_gpass and training
-        if share:
+        twin = training and bool(self.overlap_mask & 16) and not share and true_x.is_cuda
+        if share or twin:
             ov2 = False
+        fake_y2 = None
         if overlap:
             main = torch.cuda.current_stream(true_x.device)
             if self._side is None:
@@ -179,7 +185,11 @@ class TIMEBANDTrainer:
         if ov1:
             s1.wait_stream(main)
             with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step
-                fake_y = netG(true_x)
+                if twin:                         # ... and the G-phase one with it
+                    fake_y, fake_y2 = netG.twin(true_x, s2 if ov8 else None)
+                    fake_y2.record_stream(main)
+                else:
+                    fake_y = netG(true_x)
             fake_y.record_stream(main)
         if training:
             self._critic_opt = FusedRMSprop(netD, self.lr * self.lr_gammaD)
@@ -200,6 +210,8 @@ class TIMEBANDTrainer:
         with torch.set_grad_enabled(training), counts():
             if ov1:
                 main.wait_stream(s1)
+            elif twin:
+                fake_y, fake_y2 = netG.twin(true_x, s2 if ov8 else None)
             else:
                 fake_y = netG(true_x)
             if ov4 or share:
@@ -236,6 +248,8 @@ class TIMEBANDTrainer:
                 elif ov2:
                     main.wait_stream(s2)
                     fake_y = fake_y2
+                elif twin:
+                    fake_y = fake_y2             # computed with the D-phase pass (same input, same parameters)
                 else:
                     fake_y = netG(true_x)
                 if dphase is not None:

@@ -8,6 +8,8 @@ state_dict taken from a reference network loads.  (Only state_dict checkpoints a
 reference's model.py:84-95 pickles whole modules, and TIMEBANDModel.load refuses to unpickle.)  Their
 forward() is never called: all arithmetic goes through timeband_amd.ops (HIP kernels).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -56,6 +58,50 @@ class LSTMGenerator(nn.Module):
         return out.view(B, self.outseq_len, self.out_dim)
 
 
+    def twin(self, input, second_stream=None):
+        """(self(input), self(input)): the two generator forward passes of one training iteration -- the reference calls
+        netG(true_x) in the discriminator phase and again in the generator phase with unchanged parameters
+        (trainer.py:173,188) -- computed as ONE pass over 2B rows (the input twice), like LSTMDiscriminator.pair.
+        Both passes are executed in full, row by row the same arithmetic as two calls (a row's result does not depend
+        on the batch it sits in: bit-identical outputs), but the persistent recurrent kernels are bound by their
+        per-timestep latency, not by rows, so 2B rows cost little more than B.  Each returned tensor carries an autograd
+        graph of its own over its half of the BPTT stash: the two backward passes run separately, as in the reference.
+        second_stream: the stream the second pass's backward kernels are to run on (autograd runs a backward node on the
+        stream that was current when its forward node was made; default: the current one)."""
+        B = input.size(0)
+        seq, dim = self.seq_layer[0], self.dim_layer[0]
+        with torch.no_grad():
+            x2 = ops.concat2(input.contiguous(), input.contiguous())
+            r, stash = x2, []
+            for i in range(3):
+                r, st = ops.lstm_stack_raw(r, getattr(self, f"lstm{i}"), split=B)
+                stash.append(st)
+            s2 = ops.linear_act_raw(r.view(2 * B * self.hidden_dim, self.inseq_len), seq.weight.detach(), seq.bias.detach(),
+                                    ops.ACT_NONE)
+            o2 = ops.linear_act_raw(s2.view(2 * B * self.outseq_len, self.hidden_dim), dim.weight.detach(),
+                                    dim.bias.detach(), ops.ACT_TANH)
+        outs = []
+        for h in (0, 1):
+            rows = slice(h * B, (h + 1) * B)
+            ctxm = torch.cuda.stream(second_stream) if (h == 1 and second_stream is not None) else contextlib.nullcontext()
+            with ctxm:
+                outs.append(self._twin_graph(input, stash, s2, o2, rows, h))
+        return outs[0], outs[1]
+
+    def _twin_graph(self, input, stash, s2, o2, rows, h):
+        """The autograd nodes of one of twin()'s two passes, around its rows of the jointly computed buffers."""
+        B = input.size(0)
+        seq, dim = self.seq_layer[0], self.dim_layer[0]
+        r = input
+        for i in range(3):
+            r = ops.lstm_stack(r, getattr(self, f"lstm{i}"), pre=[tuple(t[rows] for t in st) for st in stash[i]])
+        n = B * self.hidden_dim
+        s = ops.linear_act(r.view(n, self.inseq_len), seq.weight, seq.bias, ops.ACT_NONE, pre=s2[h * n:(h + 1) * n])
+        n = B * self.outseq_len
+        out = ops.linear_act(s.view(n, self.hidden_dim), dim.weight, dim.bias, ops.ACT_TANH, pre=o2[h * n:(h + 1) * n])
+        return out.view(B, self.outseq_len, self.out_dim)
+
+
 class LSTMDiscriminator(nn.Module):
     """(B, T, in_dim) -> per-timestep score (B, T, 1) in (0, 1)."""
 
@@ -88,6 +134,6 @@ class LSTMDiscriminator(nn.Module):
         if real.shape != fake.shape:
             return self(real), self(fake)
         # the real half is data: nobody reads its input gradient, so the first layer does not compute it
-        out = self(torch.cat([real, fake], 0), dx_from=0 if real.requires_grad else real.size(0))
+        out = self(ops.cat2(real, fake), dx_from=0 if real.requires_grad else real.size(0))
         Dy, DGx = out.view(2, real.size(0), real.size(1), 1).unbind(0)
         return Dy, DGx
