@@ -372,22 +372,39 @@ def test_overlapped_iteration_equals_single_stream(dev, hidden):
     """TIMEBANDTrainer.iteration with the generator work on side streams (default, and each part of it
     alone: TB_OVERLAP bit mask), with and without the two generator forward passes computed as one 2B-row pass
     (bit 16, LSTMGenerator.twin), and on one stream (TB_OVERLAP=0) leave bit-identical parameters after
-    two iterations."""
+    two iterations.  Bit 32 (one generator backward over the 2B rows, the default) sums the parameter gradients
+    of the two passes in ONE reduction over 2B rows instead of pass by pass: every mask with it gives the same
+    bits as every other, and against the masks without it the discriminator and fake_y stay bit-identical after
+    one iteration while G's gradients agree to fp32 association (1e-5 of each tensor's largest entry)."""
     import bench
     cfg = dict(V=8, NT=4, To=24, Tf=24, H=hidden, L=1, B=96, N=3000)
-    results = []
-    for mask in ((21, 0, 16, 1, 2, 4, 5, 7, 13, 15, 17, 20, 29, 31) if hidden == 128 else (21, 0, 5, 16, 29)):
+
+    def run(mask, iters):
         np.random.seed(3)
         ds, trainset, trainer = bench.build(cfg, dev)
         trainer.overlap_mask = mask
-        for i in range(2):
+        for i in range(iters):
             b = trainset.gather(i * cfg["B"], cfg["B"])
-            trainer.iteration(b["encoded"], b["decoded"], training=True)
+            fake = trainer.iteration(b["encoded"], b["decoded"], training=True)
         torch.cuda.synchronize()
-        results.append([p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()])
-    for other in results[1:]:
-        for a, b in zip(results[0], other):
-            assert torch.equal(a, b)
+        params = [p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()]
+        return params, fake.clone(), [p.grad.detach().clone() for p in trainer.models.netG.parameters()], \
+            [p.detach().clone() for p in trainer.models.netD.parameters()]
+
+    plain = (29, 0, 16, 1, 2, 4, 5, 7, 13, 15, 17, 20, 21, 31) if hidden == 128 else (29, 0, 5, 16, 21)
+    joint = (49, 48, 61, 63) if hidden == 128 else (49, 48)
+    for group in (plain, joint):
+        results = [run(mask, 2)[0] for mask in group]
+        for other in results[1:]:
+            for a, b in zip(results[0], other):
+                assert torch.equal(a, b)
+    _, fa, ga, da = run(plain[0], 1)
+    _, fb, gb, db = run(joint[0], 1)
+    assert torch.equal(fa, fb)
+    for a, b in zip(da, db):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
 
 
 def test_shared_generator_pass_matches_two_passes(dev):

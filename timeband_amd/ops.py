@@ -208,7 +208,7 @@ def lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train, split=0):
 
 class _LSTMLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train, dx_from=0, pre=None):
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, train, dx_from=0, pre=None, split=0):
         # pre = (y, gates, cst): this layer's forward was already computed (LSTMGenerator.twin: one pass over the
         # rows of two forward passes) -- only the graph node is made here, around those buffers
         _need_cuda(x, w_ih, w_hh, b_ih, b_hh)
@@ -218,7 +218,7 @@ class _LSTMLayerFn(torch.autograd.Function):
         B, T, In = x.shape
         H = w_hh.shape[1]
         if pre is None:
-            y, gates, cst = lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train)
+            y, gates, cst = lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train, split)
         else:
             y, gates, cst = pre
             if y.shape != (B, T, H) or gates.shape != (B, T, 4 * H) or not (y.is_contiguous() and gates.is_contiguous()):
@@ -277,20 +277,20 @@ class _LSTMLayerFn(torch.autograd.Function):
                     t.record_stream(wg)
                 rt._wg_dirty = True
                 grads_enqueued(slots, ctx.params)      # an armed reducer records its event on THIS stream
-            return dx, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
         if slots is not None:
             grads_enqueued(slots, ctx.params)
-            return dx, None, None, None, None, None, None, None
-        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None, None
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None, None, None
 
 
-def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0, pre=None):
+def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0, pre=None, split=0):
     """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H).  dx_from: the caller promises that nobody reads
     the input gradient of the batch rows [0, dx_from) -- it is then not computed (those rows of x.grad are garbage).
     pre: see _LSTMLayerFn.forward."""
     # grad mode is off inside Function.forward, so the stash decision is taken here
     train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh)))
-    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from, pre)
+    return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from, pre, split)
 
 
 import os as _os
@@ -302,11 +302,13 @@ def _lstm_params(lstm_module, l):
             getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"))
 
 
-def lstm_stack(x, lstm_module, dx_from=0, pre=None):
+def lstm_stack(x, lstm_module, dx_from=0, pre=None, split=0):
     """Run x through the layers of a torch.nn.LSTM parameter container with the HIP kernels (dx_from: see lstm_layer;
-    it applies to the first layer, whose input is x).  pre: one (y, gates, cst) per layer, see _LSTMLayerFn.forward."""
+    it applies to the first layer, whose input is x).  pre: one (y, gates, cst) per layer, see _LSTMLayerFn.forward.
+    split: forward launches of hidden >= 256 layers in pieces of that many rows (lstm_fwd_raw)."""
     for l in range(lstm_module.num_layers):
-        x = lstm_layer(x, *_lstm_params(lstm_module, l), dx_from if l == 0 else 0, None if pre is None else pre[l])
+        x = lstm_layer(x, *_lstm_params(lstm_module, l), dx_from if l == 0 else 0, None if pre is None else pre[l],
+                       split if (lstm_module.hidden_size >= 256 and _TWIN_SPLIT) else 0)
     return x
 
 

@@ -49,8 +49,13 @@ class TIMEBANDTrainer:
         # input through the same parameters, trainer.py:173,188 -- as ONE pass over 2B rows (LSTMGenerator.twin).
         # Bit 8 with it (default since the twin pass: 6.84 -> 6.75 ms/step): the generator phase is short now, so the
         # D-phase generator backward is still running when the G-phase one could start.
-        ov = os.environ.get("TB_OVERLAP", "29")
-        self.overlap_mask = int(ov) if ov.isdigit() else 29
+        # Bit 32 (default; replaces 4 and 8): the generator's two backward passes as ONE pass over the 2B rows of the twin
+        # forward, behind the generator phase's discriminator pass -- the recurrent kernels cost the same for 2B rows
+        # as for B (three fewer latency-bound launches, no co-running in the generator phase): 6.73 -> 6.21 ms/step.
+        # The two passes' parameter gradients are then summed in one reduction over 2B rows instead of one after the
+        # other: the same sum up to fp32 association (TB_OVERLAP=29 keeps them apart, bit-identical to one stream).
+        ov = os.environ.get("TB_OVERLAP", "49")
+        self.overlap_mask = int(ov) if ov.isdigit() else 49
         self.overlap = (self.overlap_mask & 15) != 0
         # TB_SHARE_GPASS=1 (off by default; not the reference's schedule): G's parameters are the same in
         # the D phase and the G phase, so netG(true_x) is the same tensor both times and backward is linear
@@ -63,6 +68,7 @@ class TIMEBANDTrainer:
         self.wgrad_overlap = os.environ.get("TB_WGRAD_OVERLAP", "0") == "1"
         self._side = None
         self._ones = {}
+        self._marks = None      # tools/phase_times.py: list of (name, event on the main stream) per iteration
 
     def _one(self, loss):
         """d(loss)/d(loss) = 1 from a cached device scalar: backward() without autograd's ones-fill launch."""
@@ -70,6 +76,12 @@ class TIMEBANDTrainer:
         if one is None:
             one = self._ones[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
         return one
+
+    def _mark(self, name, dev):
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+            self._marks.append((name, ev))
 
     def set_config(self, config: dict = None) -> None:
         self.__dict__ = {**config, **self.__dict__}
@@ -167,9 +179,14 @@ class TIMEBANDTrainer:
         ov8 = ov8 and ov4
         share = self.share_gpass and training
         twin = training and bool(self.overlap_mask & 16) and not share and true_x.is_cuda
+        # bit 32 (needs 16): ONE generator backward pass over the 2B rows of the twin forward, behind the generator phase's
+        # discriminator pass, instead of one per phase (LSTMGenerator.twin_joint)
+        joint = twin and bool(self.overlap_mask & 32)
         if share or twin:
             ov2 = False
-        fake_y2 = None
+        if joint:
+            ov4 = ov8 = False
+        fake_y2 = out2 = None
         if overlap:
             main = torch.cuda.current_stream(true_x.device)
             if self._side is None:
@@ -180,12 +197,16 @@ class TIMEBANDTrainer:
                 if quiet is not None:
                     quiet(False)
             s1, s2 = self._side
+        self._mark("start", true_x.device)
         nloc = true_x.shape[0]
         counts = lambda: dp.batch_counts(nloc, nloc * dp.world() if n_global is None else n_global)
         if ov1:
             s1.wait_stream(main)
             with torch.cuda.stream(s1):          # D-phase generator forward, under the critic step
-                if twin:                         # ... and the G-phase one with it
+                if joint:
+                    out2, fake_y, fake_y2 = netG.twin_joint(true_x)
+                    out2.record_stream(main)     # fake_y / fake_y2 are views of its storage
+                elif twin:                       # ... and the G-phase one with it
                     fake_y, fake_y2 = netG.twin(true_x, s2 if ov8 else None)
                     fake_y2.record_stream(main)
                 else:
@@ -204,16 +225,20 @@ class TIMEBANDTrainer:
                 else:
                     with dp.replicated():
                         self.critic_step(cx, cy)
+        self._mark("critic", true_x.device)
         self.optimD.zero_grad()
         self.optimG.zero_grad()
         # discriminator phase: fake_y keeps its graph, errD.backward() reaches G too
         with torch.set_grad_enabled(training), counts():
             if ov1:
                 main.wait_stream(s1)
+            elif joint:
+                out2, fake_y, fake_y2 = netG.twin_joint(true_x)
             elif twin:
                 fake_y, fake_y2 = netG.twin(true_x, s2 if ov8 else None)
             else:
                 fake_y = netG(true_x)
+            leaf_a = fake_y
             if ov4 or share:
                 # cut the graph at fake_y: D's backward runs on this stream, G's (below) on its forward's
                 fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
@@ -268,15 +293,29 @@ class TIMEBANDTrainer:
                     # -- which does not read D -- so that D's gradient all-reduce hides under it
                     self.optimD.all_reduce_grads()
                     self.optimD.step()
+                    self._mark("dphase", true_x.device)
                 if ov4 and not share:
                     fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
                 DGx = netD(fake_y)
                 errG = self.losses.gen_loss(true_y, fake_y, DGx, presum=presum)
             if training:
-                if not (share or ov4):
+                if not (share or ov4 or joint):
                     self.optimG.begin_reduce()   # errG.backward() runs through D into G: G's last backward pass
                 errG.backward(self._one(errG))
-                if share:
+                self._mark("gphase_D", true_x.device)
+                if joint:
+                    # both generator backward passes (trainer.py:179 through fake_y's graph, :193) as one over 2B rows
+                    self.optimG.begin_reduce()
+                    g2 = ops.concat2(leaf_a.grad, fake_y.grad)
+                    if ov1:
+                        g2.record_stream(s1)
+                        s1.wait_stream(main)
+                        with torch.cuda.stream(s1):
+                            out2.backward(g2)
+                        main.wait_stream(s1)
+                    else:
+                        out2.backward(g2)
+                elif share:
                     self.optimG.begin_reduce()
                     fake_g.backward(dfake_dphase + fake_y.grad)
                     if overlap:
@@ -305,6 +344,7 @@ class TIMEBANDTrainer:
         if training:
             self.optimG.all_reduce_grads()
             self.optimG.step()
+        self._mark("end", true_x.device)
         ops.Runtime.wgrad_overlap = False
         return fake_y.detach()
 

@@ -47,16 +47,27 @@ class LSTMGenerator(nn.Module):
         """Gen-B argument order (reference source/models.py:23-31)."""
         return cls(in_dim, out_dim, in_seq, out_seq, hid_dim, n_layers, device)
 
-    def forward(self, input):
+    def forward(self, input, split=0):
         B = input.size(0)
         r = input
         for i in range(3):
-            r = ops.lstm_stack(r, getattr(self, f"lstm{i}"))
+            r = ops.lstm_stack(r, getattr(self, f"lstm{i}"), split=split)
         seq, dim = self.seq_layer[0], self.dim_layer[0]
         s = ops.linear_act(r.view(B * self.hidden_dim, self.inseq_len), seq.weight, seq.bias, ops.ACT_NONE)
         out = ops.linear_act(s.view(B * self.outseq_len, self.hidden_dim), dim.weight, dim.bias, ops.ACT_TANH)
         return out.view(B, self.outseq_len, self.out_dim)
 
+
+    def twin_joint(self, input):
+        """twin() with ONE autograd graph over the 2B rows: returns (out2, fake_a, fake_b) -- out2 (2B, Tf, V) carries
+        the graph; fake_a / fake_b are its two halves as detached leaves (requires_grad) for the discriminator phase and
+        the generator phase.  The caller runs the two generator backward passes of the reference (trainer.py:179,193) as
+        one: out2.backward(cat(fake_a.grad, fake_b.grad)) -- the parameter gradients are then summed over the 2B rows
+        in one pass instead of accumulated pass by pass (the same sum up to fp32 association)."""
+        B = input.size(0)
+        x = input.contiguous()
+        out2 = self(ops.concat2(x, x), split=B)
+        return out2, out2[:B].detach().requires_grad_(), out2[B:].detach().requires_grad_()
 
     def twin(self, input, second_stream=None):
         """(self(input), self(input)): the two generator forward passes of one training iteration -- the reference calls

@@ -1,6 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/t3
-timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3 | tee gpurun_out/t3/tests.log || exit 1
-timeout -k 10 200 python tools/aten_ops.py 2>&1 | grep aten::
-timeout -k 10 120 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['kernel_ms_per_step'])"
+mkdir -p gpurun_out/t4
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3 | tee gpurun_out/t4/tests.log || exit 1
+timeout -k 10 120 python bench.py --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/t4/bench.json | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline'], d['kernel_ms_per_step'])"
