@@ -250,8 +250,8 @@ def main():
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        from timeband_amd import dp as _dp
+        _dp.init("nccl", rank=rank, world_size=world, device_id=device)      # sets the RCCL channel cap first
         assert dist.get_world_size() == args.gpus
 
     cfg = CONFIGS[args.config]
@@ -312,13 +312,19 @@ def main():
     warm = {name: read(k) for name, k in kids.items()}
     dom = max(("lstm_fwd", "lstm_bwd"), key=lambda k: warm[k]["total_ms"]) if args.warmup > 0 else "lstm_fwd"
     lib.tb_prof_enable(kids[dom], 1)
+    from timeband_amd import dp as _dpm
+    _dpm.comm_timing(world > 1)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0           # this rank alone, before the barrier
     barrier()
     dt = time.perf_counter() - t0
     ops.check_errors(device)
+    comm_wait_ms = _dpm.comm_wait_ms()
+    _dpm.comm_timing(False)
     p = read(kids[dom])
     extra = min(5, args.steps)
     for k in kids.values():
@@ -340,10 +346,23 @@ def main():
     ops.check_errors(device)
     solo = read(kids[dom])
     trainer.overlap_mask = mask
+    per_rank = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank spread (host jitter becomes all-reduce skew) and exposed communication: the time a stream that
+        # needed reduced gradients had to wait for them
+        mine = torch.tensor([dt_rank / args.steps * 1e3, comm_wait_ms / args.steps], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ms = [float(a[0]) for a in allr]
+        cw = [float(a[1]) for a in allr]
+        per_rank = {"ms_per_step_min": round(min(ms), 4), "ms_per_step_max": round(max(ms), 4),
+                    "ms_per_step": [round(v, 4) for v in ms],
+                    "exposed_comm_ms_per_step_max": round(max(cw), 4), "exposed_comm_ms_per_step": [round(v, 4) for v in cw],
+                    "note": "per rank, own clock up to its own device sync (before the closing barrier); exposed = time "
+                            "the optimizer steps waited for the bucketed gradient all-reduces (events on their stream)"}
 
     if rank == 0:
         windows = B * world * args.steps
@@ -380,6 +399,8 @@ def main():
             "kernel_ms_per_step": {k: round(v["total_ms"] / max(1, extra), 4) for k, v in prof.items()},
             "kernel_ms_per_step_source": f"{extra} extra untimed steps with every family's event timers on",
         }
+        if per_rank is not None:
+            out["ranks"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             from oracle.torch_cpu_port import time_cpu_baseline
             threads = min(16, os.cpu_count() or 1)

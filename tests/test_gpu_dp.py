@@ -49,12 +49,32 @@ def _run_pass(dev, rank, world, nbatch=3, gb=None, critic=1):
     return score, params, trainer.optimD.flat.grad.clone(), trainer.optimG.flat.grad.clone(), trainer.losses.loss(nbatch - 1)
 
 
+def _run_cfg2(dev, iters=2):
+    """BASELINE.json configs[1] at full size (32 variables, window 128, hidden 256, batch 512): the discriminator's
+    real + fake pass is then 1024 rows -- the EXCLUSIVE 4-member launches -- beside the bucketed all-reduces."""
+    import bench
+    from timeband_amd import ops
+    np.random.seed(3)
+    cfg = bench.CONFIGS["cfg2"]
+    ds, trainset, trainer = bench.build(cfg, dev)
+    np.random.seed(3)
+    for i in range(iters):
+        b = trainset.gather(i * cfg["B"], cfg["B"])
+        trainer.iteration(b["encoded"], b["decoded"], training=True)
+    torch.cuda.synchronize()
+    err = ops.Runtime.get(dev).err.tolist()
+    assert err[0] == 0, err                      # no inter-workgroup wait timed out
+    ops.check_errors(dev)
+    return [p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()]
+
+
 def test_world1_rccl_path_is_bit_identical():
     import torch.distributed as dist
     from timeband_amd import dp
     dev = torch.device("cuda", 0)
     base = _run_pass(dev, 0, 1)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    dp.init("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    assert os.environ["NCCL_MAX_NCHANNELS"]      # the channel cap is in place before RCCL comes up
     try:
         dp.force(True)
         assert dp.active()
@@ -72,6 +92,14 @@ def test_world1_rccl_path_is_bit_identical():
             rb = b.step(fake, (0, CFG["B"], False))
             for x, y in zip(ra, rb):
                 assert torch.equal(x, y)
+        # cfg2 at full size: RCCL's all-reduce kernels on the communication stream while exclusive and clustered
+        # recurrent launches run (the co-residency argument of DESIGN.md section 8) -- no timeout, same bits
+        dp.force(False)
+        plain2 = _run_cfg2(dev)
+        dp.force(True)
+        forced2 = _run_cfg2(dev)
+        for x, y in zip(plain2, forced2):
+            assert torch.equal(x, y)
     finally:
         dp.force(False)
         dist.destroy_process_group()

@@ -32,6 +32,20 @@ _SCALE = None          # (n_local, n_global) of the batch being processed, or No
 _FORCE = os.environ.get("TB_DP_FORCE", "0") == "1"   # take the collective paths even with one rank (tests)
 
 
+def init(backend="nccl", **kw):
+    """torch.distributed.init_process_group with this path's RCCL settings (call it instead, BEFORE any collective).
+    NCCL_MAX_NCHANNELS (kept if the environment already sets it): RCCL runs one workgroup per channel, and its
+    all-reduces run on the communication stream BESIDE the clustered recurrent kernels, which need all their workgroups
+    resident.  The messages here are 1.2 MB (D) and 2.2 MB (G) of gradients in buckets of
+    >= 256 KB plus 16-byte loss sums -- latency-bound on xGMI, not bandwidth-bound -- so 8 channels (one per XCD; at
+    least one ring per xGMI link of the 7) lose nothing and bound RCCL's footprint to 8 of the 256 CUs."""
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group(backend, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
 def initialized() -> bool:
     return dist.is_available() and dist.is_initialized()
 
@@ -255,6 +269,42 @@ def all_gather_cat(t):
 # ---------------------------------------------------------------------------------------------------
 # bucketed gradient all-reduce
 # ---------------------------------------------------------------------------------------------------
+# Exposed communication: how long the stream that needs the reduced gradients had to WAIT for them (bench.py
+# --gpus N reports it).  With timing on, _FlatOptimizer.all_reduce_grads() brackets its wait with two events.
+_COMM_EVENTS = None
+
+
+def comm_timing(on: bool):
+    global _COMM_EVENTS
+    _COMM_EVENTS = [] if on else None
+
+
+def comm_bracket(device):
+    """An event on the current stream now (None if timing is off); pair it with comm_bracket_end()."""
+    if _COMM_EVENTS is None or device.type != "cuda":
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
+def comm_bracket_end(begin, device):
+    if begin is not None and _COMM_EVENTS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(device))
+        _COMM_EVENTS.append((begin, ev))
+
+
+def comm_wait_ms() -> float:
+    """Sum of the bracketed waits so far (synchronise the device first); clears the list."""
+    global _COMM_EVENTS
+    if not _COMM_EVENTS:
+        return 0.0
+    total = sum(b.elapsed_time(e) for b, e in _COMM_EVENTS)
+    _COMM_EVENTS = []
+    return total
+
+
 class GradReducer:
     """Sum all-reduce of one network's flat gradient buffer in buckets, overlapped with BPTT.
 

@@ -145,7 +145,9 @@ class _FlatOptimizer:
         if self._reducer is None:
             self._reducer = dp.GradReducer(self.flat)
             self._reducer.arm()
+        t0 = dp.comm_bracket(self.flat.grad.device)
         self._reducer.finish()
+        dp.comm_bracket_end(t0, self.flat.grad.device)
         self._reducer = None
 
 
