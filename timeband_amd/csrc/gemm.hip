@@ -44,6 +44,7 @@ struct GemmArgs {
   int b_shift, b_period;
   int vecA, vecB;
   int bytesA, bytesB;    // extents of the operands for the bounds-checked buffer loads
+  int xcd_map;           // gemm_big_kernel: XCD-aware item numbering (TB_GEMM_XMAP=0: off)
 };
 
 template <int LAY, int ROWS>
@@ -390,6 +391,232 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
   }
 }
 
+// ---- the large-K products (weight gradients: K = rows x steps; input gradients: K = 4H) -----------------------------
+// The 128 x 128 kernel above spends most of its time off the matrix pipe: per MFMA it converts and stores 43 operand
+// elements (3 vector instructions each for the bf16 hi / lo split, ds_write_b64 at ~85 B/clk) and crosses two
+// barriers per 32-deep k-tile with one LDS image.  This variant is for products whose k loop is long enough to
+// amortise a bigger tile: 256 x 128 per workgroup of 8 waves (4 x 2, each wave the same 64 x 64 patch as above, two
+// waves per SIMD), 32 elements per MFMA; LDS images double-buffered -- the next tile is stored while the current one is
+// read, ONE barrier per k-tile --; operand tiles fetched two k-tiles ahead into two register sets.  One workgroup per
+// CU (123 KB of LDS).  Measured (tools/micro/wgrad_micro.py, hidden 256, 512 rows x 128 steps): dW_hh 199 -> 157 us,
+// dW_ih 97 -> 76, dx 96 -> 83; the iteration 6.22 -> 6.03 ms.  Tried and NOT kept: fixed wave roles (waves 0-3 MFMA on
+// 128 x 64 patches, waves 4-7 load / split / store: 239 us -- the four loader waves cannot keep two tiles in flight
+// AND convert them in the time the MFMA waves need); a per-workgroup rotation of the k loop against HBM channel
+// camping (no change).
+template <int LAY, int ROWS, int NT>
+struct TileN {
+  static constexpr int LD = LAY == 0 ? BK + 8 : ROWS + 8;
+  static constexpr int ELEMS = LAY == 0 ? ROWS * LD : BK * LD;
+  static constexpr int NCHUNK = ROWS * BK / 4;
+  static constexpr int NCH = NCHUNK / NT;
+  static_assert(NCHUNK % NT == 0, "chunk count must tile the block");
+  static __device__ __forceinline__ void where(int c, int& r, int& k) {
+    const int e = threadIdx.x + NT * c;
+    if (LAY == 0) { r = e >> 3; k = (e & 7) * 4; }
+    else { k = e / (ROWS / 4); r = (e % (ROWS / 4)) * 4; }
+  }
+  static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, long ld, int r0, int rlim, int k0, int klim,
+                                              int shift, int period, f32x4 (&v)[NCH]) {
+    constexpr int kOob = 0x7FFFFFF0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int r, k;
+      where(c, r, k);
+      r += r0; k += k0;
+      bool ok = r < rlim && k < klim;
+      if (LAY == 1 && shift) {
+        ok = ok && (k % period) >= shift;
+        k -= shift;
+      }
+      const long e0 = LAY == 0 ? (long)r * ld + k : (long)k * ld + r;
+      v[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (int)(e0 * 4) : kOob, 0, 0));
+    }
+  }
+  static __device__ __forceinline__ void store(unsigned short* hi, unsigned short* lo, const f32x4 (&v)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int r, k;
+      where(c, r, k);
+      u32x2 sh, sl;
+      tb_split4(v[c], sh, sl);
+      const int off = LAY == 0 ? r * LD + k : k * LD + r;
+      *reinterpret_cast<u32x2*>(hi + off) = sh;
+      *reinterpret_cast<u32x2*>(lo + off) = sl;
+    }
+  }
+  static __device__ __forceinline__ bf16x8 frag(const unsigned short* img, int row, int col, int q) {
+    if (LAY == 0) return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(img + (row + col) * LD + q * 8));
+    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+    const unsigned short* p0 = img + (q * 8 + (col >> 2)) * LD + row + 4 * (col & 3);
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * LD));
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    return __builtin_bit_cast(bf16x8, (u32x4){ua[0], ua[1], ub[0], ub[1]});
+  }
+};
+
+constexpr int kBigBM = 256, kBigBN = 128, kBigNT = 512;
+template <int LAY_A, int LAY_B>
+constexpr size_t big_lds_bytes() {
+  return (size_t)2 * 2 * (TileN<LAY_A, kBigBM, kBigNT>::ELEMS + TileN<LAY_B, kBigBN, kBigNT>::ELEMS) * sizeof(unsigned short) +
+         (size_t)8 * 16 * (64 + 4) * sizeof(float);
+}
+
+template <int LAY_A, int LAY_B>
+__global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
+  constexpr int BM = kBigBM, BN = kBigBN, NT = kBigNT, WGN = 2, TM = 4, TN = 4;
+  using TA = TileN<LAY_A, BM, NT>;
+  using TB = TileN<LAY_B, BN, NT>;
+  constexpr int CW = TN * 16, PLD = CW + 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  // [image][Ah | Al | Bh | Bl], then the epilogue patches
+  constexpr int BUF = 2 * (TA::ELEMS + TB::ELEMS);
+  float* patch_all = reinterpret_cast<float*>(lds + 2 * BUF);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int col = lane & 15, q = lane >> 4;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int mtiles = (a.M + BM - 1) / BM, ntiles = (a.N + BN - 1) / BN;
+  const int total = mtiles * ntiles * a.splits;
+  const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.bytesA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, a.bytesB, 0x00020000);
+  // Work items.  The tiles of ONE k-split read the same rows of A and B: they go to workgroups of one XCD (blocks with
+  // equal blockIdx % 8 under the round-robin placement), so that the XCD's L2 serves the re-reads (2-4 %).
+  const int T_ = mtiles * ntiles;
+  const bool xmap = (gridDim.x & 7) == 0 && a.splits > 1 && a.xcd_map;
+  const int vtotal = xmap ? T_ * ((a.splits + 7) / 8) * 8 : total;
+  for (int w = blockIdx.x; w < vtotal; w += gridDim.x) {
+    int z, r;
+    if (xmap) {
+      const int slot = w >> 3;
+      z = (w & 7) + 8 * (slot / T_);
+      r = slot % T_;
+      if (z >= a.splits) continue;
+    } else {
+      z = w / T_;
+      r = w % T_;
+    }
+    const int m0 = (r / ntiles) * BM, n0 = ((r + r / ntiles) % ntiles) * BN;
+    const int kbeg = z * a.kchunk, kend = min(a.K, kbeg + a.kchunk);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    f32x4 ra0[TA::NCH], rb0[TB::NCH], ra1[TA::NCH], rb1[TB::NCH];
+    auto issue = [&](int kt, f32x4 (&ra)[TA::NCH], f32x4 (&rb)[TB::NCH]) {
+      if (kt < nk) {
+        TA::load(rA, a.lda, m0, a.M, kbeg + kt * BK, kend, 0, 1, ra);
+        TB::load(rB, a.ldb, n0, a.N, kbeg + kt * BK, kend, a.b_shift, a.b_period, rb);
+      }
+    };
+    auto images = [&](int b, unsigned short*& Ah, unsigned short*& Al, unsigned short*& Bh, unsigned short*& Bl) {
+      Ah = lds + b * BUF; Al = Ah + TA::ELEMS; Bh = Al + TA::ELEMS; Bl = Bh + TB::ELEMS;
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bv;
+    {
+      const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (a.bias && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb2_ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias2, 0, (a.bias2 && a.splits == 1) ? a.N * 4 : 0, 0x00020000);
+      const int nb = n0 + wn * CW + (lane % (CW / 4)) * 4;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        bv[r4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb_, (nb + r4) * 4, 0, 0)) +
+                 __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb2_, (nb + r4) * 4, 0, 0));
+    }
+    issue(0, ra0, rb0);
+    issue(1, ra1, rb1);
+    {
+      unsigned short *Ah, *Al, *Bh, *Bl;
+      images(0, Ah, Al, Bh, Bl);
+      TA::store(Ah, Al, ra0);
+      TB::store(Bh, Bl, rb0);
+    }
+    issue(2, ra0, rb0);
+    __syncthreads();
+    // one k-tile: MFMAs on image `kt & 1`; the tile after it (already in `ra`/`rb`) goes to the other image meanwhile,
+    // and the registers it leaves are refilled with the tile three ahead
+    auto half = [&](int kt, f32x4 (&ra)[TA::NCH], f32x4 (&rb)[TB::NCH]) {
+      unsigned short *Ah, *Al, *Bh, *Bl, *nAh, *nAl, *nBh, *nBl;
+      images(kt & 1, Ah, Al, Bh, Bl);
+      images((kt + 1) & 1, nAh, nAl, nBh, nBl);
+      bf16x8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = TB::frag(Bh, (wn * TN + j) * 16, col, q);
+        bl[j] = TB::frag(Bl, (wn * TN + j) * 16, col, q);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bf16x8 ah = TA::frag(Ah, (wm * TM + i) * 16, col, q);
+        const bf16x8 al = TA::frag(Al, (wm * TM + i) * 16, col, q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        if (i == 0 && kt + 1 < nk) TA::store(nAh, nAl, ra);
+        if (i == 1 && kt + 1 < nk) TB::store(nBh, nBl, rb);
+        if (i == 2) issue(kt + 3, ra, rb);
+      }
+      __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      half(kt, ra1, rb1);
+      if (kt + 1 < nk) half(kt + 1, ra0, rb0);
+    }
+    // epilogue: each wave turns its 16 x 64 patches through a private LDS buffer (rows of 256 contiguous bytes)
+    float* out = a.splits > 1 ? a.slab + (size_t)z * a.M * a.N : a.C;
+    const long ldo = a.splits > 1 ? a.N : a.ldc;
+    float* pw = patch_all + wave * 16 * PLD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(pw + col * PLD + j * 16 + q * 4) = acc[i][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < TN; ++k) {
+        const int idx = k * 64 + lane, row = idx / (CW / 4), c4 = idx % (CW / 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(pw + row * PLD + c4 * 4);
+        const int m = m0 + (wm * TM + i) * 16 + row;
+        const int n = n0 + wn * CW + c4 * 4;
+        if (m >= a.M || n >= a.N) continue;
+        if (a.splits == 1) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            v[r4] += bv[r4];
+            if (a.act == 1) v[r4] = tanhf(v[r4]);
+            else if (a.act == 2) v[r4] = tb_sigmoid(v[r4]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(out + (long)m * ldo + n) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // the next item's first store must not overtake a slower wave's last fragment reads
+  }
+}
+
+template <int LAY_A, int LAY_B>
+int launch_big_t(const GemmArgs& a, dim3 grid, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<LAY_A, LAY_B>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const size_t lds_bytes = big_lds_bytes<LAY_A, LAY_B>();
+  hipLaunchKernelGGL((gemm_big_kernel<LAY_A, LAY_B>), grid, dim3(kBigNT), lds_bytes, stream, a);
+  return TB_OK;
+}
+
+int launch_big(const GemmArgs& a, int transA, int transB, dim3 grid, hipStream_t stream) {
+  if (transA == 0 && transB == 0) return launch_big_t<0, 0>(a, grid, stream);
+  if (transA == 0 && transB == 1) return launch_big_t<0, 1>(a, grid, stream);
+  if (transA == 1 && transB == 1) return launch_big_t<1, 1>(a, grid, stream);
+  return launch_big_t<1, 0>(a, grid, stream);
+}
+
 // Split-K reduction in a fixed order (bitwise reproducible), two levels so that it parallelises over the
 // splits as well as over the elements: splitk_group sums groups of kGroup consecutive slabs into the
 // first slab of each group; splitk_final sums the group leaders, adds the bias, applies the activation.
@@ -569,15 +796,22 @@ static int gemm_launch_one(const float* A, long lda, int transA, const float* B,
     return tb_set_error(TB_ERR_UNSUPPORTED, "gemm: operand larger than 2 GiB (%lld / %lld bytes)", exA, exB);
   a.bytesA = (int)exA;
   a.bytesB = (int)exB;
+  static const int xcd_map = []() { const char* e = getenv("TB_GEMM_XMAP"); return e ? atoi(e) : 1; }();
+  a.xcd_map = xcd_map;
   // tile shape by output width
-  const int cfg = N <= 32 ? 0 : (N <= 64 ? 1 : 2);
+  // TB_GEMM_BIG (default 1): the 256 x 128 / 512-thread kernel for long k loops over wide outputs (gemm_big_kernel)
+  static const int big_on = []() { const char* e = getenv("TB_GEMM_BIG"); return e ? atoi(e) : 1; }();
+  const bool out_vec_big = ((reinterpret_cast<uintptr_t>(ws) & 15) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                           (ldc & 3) == 0 && (N & 3) == 0 && (((size_t)M * N) & 3) == 0;
+  const bool big = big_on && N > 64 && M >= 256 && K >= 512 && a.vecA && a.vecB && out_vec_big;
+  const int cfg = big ? 3 : (N <= 32 ? 0 : (N <= 64 ? 1 : 2));
   const int BM = cfg == 2 ? 128 : 256, BN = cfg == 0 ? 32 : (cfg == 1 ? 64 : 128);
   const int mt = (M + BM - 1) / BM, nt = (N + BN - 1) / BN;
   const long tiles = (long)mt * nt;
   int splits = 1;
   const int cus = tb_num_cus();
   if (tiles < cus && K >= 32 * BK && ws) {
-    splits = (int)((2L * cus + tiles - 1) / tiles);
+    splits = (int)(((big ? 1L : 2L) * cus + tiles - 1) / tiles);
     const int maxs = K / (8 * BK);
     if (splits > maxs) splits = maxs;
     if (splits > 512) splits = 512;
@@ -598,10 +832,13 @@ static int gemm_launch_one(const float* A, long lda, int transA, const float* B,
   }
   // persistent grid: as many blocks as stay resident (2 per CU by registers, 3 for the narrow tiles)
   long items = tiles * splits;
-  const long resident = (long)cus * (cfg == 0 ? 3 : 2);
+  const long resident = (long)cus * (cfg == 0 ? 3 : (cfg == 3 ? 1 : 2));
   dim3 grid((unsigned)(items < resident ? items : resident));
   tb_prof_begin(TB_K_GEMM, stream);
-  if (cfg == 0) launch_cfg<256, 32, 4, 1>(a, transA, transB, grid, stream);
+  if (cfg == 3) {
+    const int rc = launch_big(a, transA, transB, grid, stream);
+    if (rc) return rc;
+  } else if (cfg == 0) launch_cfg<256, 32, 4, 1>(a, transA, transB, grid, stream);
   else if (cfg == 1) launch_cfg<256, 64, 4, 1>(a, transA, transB, grid, stream);
   else launch_cfg<128, 128, 2, 2>(a, transA, transB, grid, stream);
   TB_LAUNCH_CHECK("gemm_bf16x3_kernel");
