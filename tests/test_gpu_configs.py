@@ -407,6 +407,35 @@ def test_overlapped_iteration_equals_single_stream(dev, hidden):
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
 
 
+@pytest.mark.parametrize("mask", [49, 29])
+def test_cpp_extension_path_equals_python_path(dev, mask, monkeypatch):
+    """The C++ extension's autograd Functions (csrc/ext.cpp, the default) and the Python ones of ops.py (TB_EXT=0) drive the
+    same kernels with the same arguments: bit-identical parameters after two iterations."""
+    import bench
+    from timeband_amd import ops
+    cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
+
+    def run():
+        np.random.seed(3)
+        ds, trainset, trainer = bench.build(cfg, dev)
+        trainer.overlap_mask = mask
+        for i in range(2):
+            b = trainset.gather(i * cfg["B"], cfg["B"])
+            trainer.iteration(b["encoded"], b["decoded"], training=True)
+        torch.cuda.synchronize()
+        ops.check_errors(dev)
+        return [p.detach().clone() for n in (trainer.models.netD, trainer.models.netG) for p in n.parameters()]
+
+    assert ops._load_ext() is not None, "the C++ extension is the product's default path"
+    with_ext = run()
+    monkeypatch.setenv("TB_EXT", "0")
+    monkeypatch.setattr(ops, "_EXT", None)
+    assert ops._ext() is None
+    without = run()
+    for a, b in zip(with_ext, without):
+        assert torch.equal(a, b)
+
+
 def test_shared_generator_pass_matches_two_passes(dev):
     """TB_SHARE_GPASS: one generator forward and one backward with the summed upstream gradient against
     the reference's schedule (two identical forwards, two backwards): same fake_y bit for bit, parameters

@@ -66,6 +66,41 @@ def _build(objdir, LIB, FLAGS, verbose, jobs):
     return LIB
 
 
+EXT = os.path.join(HERE, "_tbext.so")
+EXT_SRC = os.path.join(CSRC, "ext.cpp")
+
+
+def ext_needs_build():
+    if not os.path.exists(EXT):
+        return True
+    t = os.path.getmtime(EXT)
+    hdr = os.path.join(os.path.dirname(HERE), "include", "timeband_hip.h")
+    return any(os.path.getmtime(d) > t for d in (EXT_SRC, hdr))
+
+
+def build_ext(force=False, verbose=True):
+    """The thin PyTorch-ROCm C++ extension (csrc/ext.cpp: torch::autograd::Functions over the C-ABI) -> timeband_amd/_tbext.so.
+    Host C++ only (g++): it contains no kernels and links against libtimeband_hip.so next to it."""
+    if not force and not ext_needs_build():
+        return EXT
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", "-I/opt/rocm/include",
+                                                    f"-I{os.path.join(os.path.dirname(HERE), 'include')}"]
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-sign-compare",
+           "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_tbext", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, EXT_SRC, "-o", EXT,
+           f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+           f"-L{HERE}", "-l:libtimeband_hip.so", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return EXT
+
+
 def _drain(procs):
     while procs:
         src, p = procs.pop(0)
@@ -78,3 +113,5 @@ def _drain(procs):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, stamps="--stamps" in sys.argv))
+    if "--stamps" not in sys.argv:
+        print(build_ext(force="--force" in sys.argv))

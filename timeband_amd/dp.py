@@ -330,6 +330,7 @@ class GradReducer:
         self.fired = [False] * len(self.flat.buckets)
         self.handles = []
         ops._REDUCERS.append(self)
+        ops.reducers_changed()
 
     def notify(self, params):
         if self.pending is None:
@@ -359,6 +360,7 @@ class GradReducer:
             return
         if self in ops._REDUCERS:
             ops._REDUCERS.remove(self)
+            ops.reducers_changed()
         for b in range(len(self.flat.buckets)):
             if not self.fired[b]:
                 self._fire(b)

@@ -12,6 +12,40 @@ from . import _lib, dp
 
 ACT_NONE, ACT_TANH, ACT_SIGMOID = 0, 1, 2
 
+# The C++ extension (csrc/ext.cpp -> _tbext.so, built by timeband_amd.build.build_ext): torch::autograd::Functions for the
+# LSTM layer, Linear (+ activation) and the head over the same C-ABI -- one call into C++ per op instead of ~20 ctypes /
+# allocator / stream look-ups from the autograd.Functions below, which stay as the reference implementation
+# (TB_EXT=0 selects them; tests compare the two bit for bit).
+_EXT = None
+
+
+def _load_ext():
+    global _EXT
+    import os
+    if os.environ.get("TB_EXT", "1") == "0":
+        return None
+    if _EXT is None:
+        _lib.load()            # libtimeband_hip.so first (it has to bind to torch's HIP runtime)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_tbext.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `python -m timeband_amd.build` "
+                               "(or set TB_EXT=0 for the Python autograd path over the same kernels)")
+        from . import _tbext
+        _tbext.set_grads_hook(grads_enqueued)
+        _EXT = _tbext
+    return _EXT
+
+
+def _ext():
+    """The extension module, or None when the Python path is selected (TB_EXT=0, or the weight-gradient side stream)."""
+    if Runtime.wgrad_overlap:
+        return None
+    return _EXT if _EXT is not None else _load_ext()
+
+
+def _slot(p):
+    return getattr(p, "_tb_grad_slot", None) if (p is not None and p.requires_grad) else None
+
 
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
@@ -52,6 +86,10 @@ class Runtime:
             _lib.call("tb_init", device.index if device.index is not None else torch.cuda.current_device())
         self.err = torch.zeros(4, dtype=torch.int32, device=device)
         self._ws = {}       # one workspace per stream: launches on different streams may run concurrently
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        ext = _load_ext()
+        if ext is not None:
+            ext.set_runtime(self.index, self.err)    # the extension shares the error words and owns the co-residency guard
 
     @classmethod
     def get(cls, device):
@@ -96,6 +134,8 @@ class Runtime:
     # An EXCLUSIVE launch (tb_lstm_exclusive: workgroups of ~390 registers, nothing clustered fits beside them) waits
     # for every other stream's clustered launch, and every later clustered launch elsewhere waits for it.
     def clustered_begin(self, exclusive=False):
+        if _EXT is not None:          # one guard state for both paths: the extension's
+            return _EXT.clustered_begin(self.index, bool(exclusive))
         cl = self.__dict__.setdefault("_clustered", {})
         if not cl:
             return
@@ -115,6 +155,8 @@ class Runtime:
             cur.wait_event(ev)
 
     def clustered_end(self, exclusive=False):
+        if _EXT is not None:
+            return _EXT.clustered_end(self.index, bool(exclusive))
         cl = self.__dict__.setdefault("_clustered", {})
         cur = torch.cuda.current_stream(self.device)
         self._cl_seq = getattr(self, "_cl_seq", 0) + 1
@@ -161,6 +203,12 @@ def _slots(need, *params):
 _REDUCERS = []
 
 
+def reducers_changed():
+    """dp.GradReducer.arm / finish: the extension's backward passes call grads_enqueued only while a reducer listens."""
+    if _EXT is not None:
+        _EXT.arm_grads_hook(bool(_REDUCERS))
+
+
 def grads_enqueued(slots, params):
     if _REDUCERS and slots is not None:
         done = [p for s_, p in zip(slots, params) if s_ is not None]
@@ -176,6 +224,10 @@ def lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, train, split=0):
     launched in pieces of `split` rows (rows are independent: the same bits whichever way the batch is cut -- it keeps a
     hidden-256 layer of more than 512 rows on the 8-member cluster layout, which may share the chip with another
     clustered launch, instead of the exclusive 4-member one)."""
+    ext = _ext()
+    if ext is not None:
+        Runtime.get(x.device)
+        return tuple(ext.lstm_fwd_raw(x, w_ih, w_hh, b_ih, b_hh, bool(train), int(split)))
     x, w_ih, w_hh, b_ih, b_hh = (_f32c(t) for t in (x, w_ih, w_hh, b_ih, b_hh))
     B, T, In = x.shape
     H = w_hh.shape[1]
@@ -288,6 +340,14 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, dx_from=0, pre=None, split=0):
     """One nn.LSTM layer (batch_first, zero initial state) -> (B,T,H).  dx_from: the caller promises that nobody reads
     the input gradient of the batch rows [0, dx_from) -- it is then not computed (those rows of x.grad are garbage).
     pre: see _LSTMLayerFn.forward."""
+    ext = _ext()
+    if ext is not None:
+        if not x.is_cuda:
+            _need_cuda(x)
+        Runtime.get(x.device)
+        py, pg, pc = pre if pre is not None else (None, None, None)
+        return ext.lstm_layer(x, w_ih, w_hh, b_ih, b_hh, int(dx_from), int(split), _slot(w_ih), _slot(w_hh), _slot(b_ih),
+                              _slot(b_hh), py, pg, pc)
     # grad mode is off inside Function.forward, so the stash decision is taken here
     train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (x, w_ih, w_hh, b_ih, b_hh)))
     return _LSTMLayerFn.apply(x, w_ih, w_hh, b_ih, b_hh, train, dx_from, pre, split)
@@ -328,6 +388,9 @@ def lstm_stack_raw(x, lstm_module, split=0):
 # ----------------------------------------------------------------------------------------------
 def linear_act_raw(x, W, b, act):
     """act(x @ W.T + b) for a 2-D x, no autograd (GEMM tiles; any output width)."""
+    ext = _ext()
+    if ext is not None:
+        return ext.linear_act_raw(x, W, b, int(act))
     x, W = _f32c(x), _f32c(W)
     b = _f32c(b) if b is not None else None
     M, K = x.shape
@@ -437,6 +500,12 @@ def _aligned16(*ts):
 
 def linear_act(x2d, W, b, act=ACT_NONE, pre=None):
     """act(x2d @ W.T + b) for a 2-D x.  pre: see _LinearActFn.forward."""
+    ext = _ext()
+    if ext is not None:
+        if not x2d.is_cuda:
+            _need_cuda(x2d)
+        Runtime.get(x2d.device)
+        return ext.linear_act(x2d, W, b, int(act), _slot(W), _slot(b), pre)
     if pre is None and W.shape[0] == 1 and _lib.load().tb_head_supported(W.shape[1]) and x2d.is_contiguous() \
             and W.is_contiguous() and _aligned16(x2d, W):
         return _HeadFn.apply(x2d, W, b, act)

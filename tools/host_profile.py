@@ -18,7 +18,7 @@ B = cfg["B"]
 
 
 def step(i):
-    b = trainset.gather(i * B, B)
+    b = trainset.gather((i % (len(trainset) // B)) * B, B)
     trainer.iteration(b["encoded"], b["decoded"], training=True)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How long does the host take to ENQUEUE one training iteration (no synchronisation), next to the
-GPU time of the iteration?  If the two are close the step is host-bound.   usage: python tools/host_time.py"""
+GPU time of the iteration?  If the two are close the step is host-bound.   usage: python tools/host_time.py [cfg1|cfg2]"""
 import os
 import sys
 import time
@@ -10,13 +10,13 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 dev = torch.device("cuda", 0)
-cfg = bench.CONFIGS["cfg2"]
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
 ds, trainset, trainer = bench.build(cfg, dev)
 B = cfg["B"]
 
 
 def step(i):
-    b = trainset.gather(i * B, B)
+    b = trainset.gather((i % (len(trainset) // B)) * B, B)
     trainer.iteration(b["encoded"], b["decoded"], training=True)
 
 
