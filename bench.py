@@ -161,10 +161,14 @@ def run_clean(args, cfg, device):
         if state["i"] == nlaunch:
             state["i"] = 0
             post.reset()
-        batch = full.gather(state["i"] * B, B)
+        i0 = state["i"] * B
         state["i"] += 1
         with torch.no_grad():
-            post.step(netG(batch["encoded"])[:, :Tf])
+            if args.gathered:      # the round-2 path: materialise the encoder windows, project every (window, step) row
+                post.step(netG(full.gather(i0, B)["encoded"])[:, :Tf])
+            else:                  # the cleaner's path (TIMEBANDCleaner.clean_arrays): windows read in place
+                first = full.row0 + To + (full.w0 + i0) * ds.stride
+                post.step(netG.infer_windows(ds.series_dev, first, B, ds.stride)[:, :Tf])
 
     kids = {"lstm_fwd": _lib.K_LSTM_FWD, "gemm": _lib.K_GEMM, "band": _lib.K_BAND, "gather": _lib.K_GATHER}
 
@@ -200,7 +204,7 @@ def run_clean(args, cfg, device):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "rows_per_s": round(value, 1),
-           "config": {"workload": f"cfg5: cleaning pass (window gather + G forward + band + adjust), V={V} E={E} window={To} "
+           "config": {"workload": f"cfg5: cleaning pass ({'window gather + ' if args.gathered else 'windows in place, '}G forward + band + adjust), V={V} E={E} window={To} "
                                   f"hidden={H} {B} windows/launch, series of {N} rows resident in HBM",
                       "series_rows": N, "windows": len(full), "dataset_setup_s": round(setup_s, 2)},
            "roofline": {"bound": "hbm", "kernel": "whole cleaning launch (all kernels of one step)",
@@ -220,6 +224,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="series length (cfg5; default: the config's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full", action="store_true", help="also time band/adjust/scores inside the step")
+    ap.add_argument("--gathered", action="store_true", help="cfg5: gather the encoder windows (round-2 path) instead of reading them in place")
     ap.add_argument("--share-gpass", action="store_true",
                     help="NOT the headline schedule: one generator forward/backward per iteration instead of the "
                          "reference's two identical forwards (see TIMEBANDTrainer.share_gpass)")
@@ -397,6 +402,9 @@ def main():
                                   "frac": round(abw * value / world / (HBM_PEAK_GBS * 1e9), 5)},
             "roofline_gemm": pmc_mfma() if args.config == "cfg2" else None,
             "kernel_ms_per_step": {k: round(v["total_ms"] / max(1, extra), 4) for k, v in prof.items()},
+            "kernel_launches_per_step": {k: round(v["launches"] / max(1, extra), 2) for k, v in prof.items()},
+            "algo_bytes_per_launch": {k: round(v["algo_bytes"] / max(1, v["launches"]), 1) for k, v in prof.items()
+                                      if v["algo_bytes"] > 0},
             "kernel_ms_per_step_source": f"{extra} extra untimed steps with every family's event timers on",
         }
         if per_rank is not None:

@@ -79,6 +79,15 @@ size_t tb_lstm_wgrad_workspace_bytes(int in_dim, int H);
 int tb_lstm_wgrad(const float* x, const float* y, const float* dgates, float* dw_ih, float* dw_hh, int B, int T,
                   int in_dim, int H, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Inference over the OVERLAPPING stride-`stride` windows of a series (cleaning / prediction: source/cleaner.py:67-68,
+ * source/predictor.py:68-69 over the windows of source/dataset.py:207-212): window b's pre-activations at step t are row
+ * first_row + b * stride + t of `pseries` (series_rows x 4H) = x.W_ih^T + b_ih + b_hh computed ONCE per series row by the
+ * caller (tb_linear_act_fwd with the summed bias) instead of once per (window, step) -- T / stride times fewer projection
+ * flops, and the windows' encoder rows are never gathered.  y (B,T,H); pseries is only read.  Per row the same arithmetic
+ * as tb_lstm_fwd on the gathered windows with the projection by GEMM: bit-identical outputs. */
+int tb_lstm_fwd_windows(const float* pseries, long series_rows, long first_row, long stride, const float* w_hh, float* y,
+                        int B, int T, int H, void* ws, size_t ws_bytes, int* err, void* stream);
+
 /* tb_lstm_fwd for callers that CANNOT ALLOCATE (tight serving loops such as the cleaning pass, harnesses
  * that forbid hipMalloc, code that runs while a capture is open elsewhere).  No counterpart in the reference.  Same arguments
  * and results as tb_lstm_fwd minus the workspace: the exchange area (handshake tags + h ring) is a static

@@ -436,6 +436,36 @@ def test_cpp_extension_path_equals_python_path(dev, mask, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("E,V,To,Tf,H,L,stride", [(132, 128, 24, 24, 64, 1, 1), (516, 512, 48, 48, 64, 1, 1), (100, 96, 16, 8, 512, 1, 2),
+                                                   (72, 68, 12, 12, 64, 2, 1), (11, 7, 48, 48, 64, 1, 1), (36, 32, 20, 20, 256, 1, 3)])
+def test_infer_windows_equals_gathered_windows(dev, E, V, To, Tf, H, L, stride):
+    """LSTMGenerator.infer_windows (the cleaner's path: overlapping windows read in place from the series, first projection
+    once per series row, tb_lstm_fwd_windows) against the generator on the gathered windows.  Where the gathered path
+    projects by GEMM too (encoder width > 64) the two do the same arithmetic per row: bit-identical.  Narrow encoders
+    are fused into the recurrent kernel on the gathered path (another summation order): 1e-5."""
+    from timeband_amd import ops
+    from timeband_amd.utils.lstm_layer import LSTMGenerator
+    torch.manual_seed(5)
+    netG = LSTMGenerator(E, V, To, Tf, H, L).to(dev)
+    rows, nwin = 400 * stride, 150
+    series = (torch.rand(rows, E) * 2 - 1).to(dev)
+    tcols = torch.arange(V, dtype=torch.int32, device=dev)
+    first = To + 7
+    assert first + (nwin - 1) * stride + Tf <= rows
+    enc, _ = ops.window_gather(series, tcols, first, nwin, To, Tf, stride=stride)
+    with torch.no_grad():
+        want = netG(enc)
+    got = netG.infer_windows(series, first, nwin, stride)
+    torch.cuda.synchronize()
+    ops.check_errors(dev)
+    if E > 64:
+        assert torch.equal(got, want)
+    else:
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    with pytest.raises(RuntimeError):
+        netG.infer_windows(series, To - 1, 4, stride)          # the first window would start before the series
+
+
 def test_shared_generator_pass_matches_two_passes(dev):
     """TB_SHARE_GPASS: one generator forward and one backward with the summed upstream gradient against
     the reference's schedule (two identical forwards, two backwards): same fake_y bit for bit, parameters

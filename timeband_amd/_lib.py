@@ -32,6 +32,7 @@ SIGNATURES = {
     "tb_lstm_exclusive": (I, [I, I, I, I]),
     "tb_lstm_workspace_bytes": (Z, [I, I, I, I, I]),
     "tb_lstm_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P, P]),
+    "tb_lstm_fwd_windows": (I, [P, L, L, L, P, P, I, I, I, P, Z, P, P]),
     "tb_lstm_wgrad_workspace_bytes": (Z, [I, I]),
     "tb_lstm_wgrad": (I, [P, P, P, P, P, I, I, I, I, I, P, Z, P]),
     "tb_lstm_static_init": (I, []),

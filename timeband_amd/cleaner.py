@@ -2,6 +2,8 @@
 
 clean(dataset) returns (outputs_df, bands_df) like the reference; `clean_arrays` returns the device
 tensors without building DataFrames (what the wide 512-variable / 10M-row case uses)."""
+import os
+
 import torch
 
 from .postprocess import BandAdjust
@@ -21,9 +23,17 @@ class TIMEBANDCleaner:
                           keep_outputs=True)
         netG = self.models.netG
         dev = self.device
+        # the product's own loader hands out window POSITIONS: the generator then reads the overlapping windows in place
+        # from the device-resident series (no gathered copy, the first projection once per series row); any other
+        # iterable of {"encoded": ...} batches (the reference's DataLoader shape) works as before
+        in_place = hasattr(dataset, "positions") and os.environ.get("TB_CLEAN_INPLACE", "1") != "0"
         with torch.no_grad():
-            for data in dataset:
-                fake_y = netG(data["encoded"].to(dev))[:, : self.forecast_len]
+            for data in (dataset.positions() if in_place else dataset):
+                if "windows" in data:
+                    first, count, stride = data["windows"]
+                    fake_y = netG.infer_windows(self.dataset.series_dev, first, count, stride)[:, : self.forecast_len]
+                else:
+                    fake_y = netG(data["encoded"].to(dev))[:, : self.forecast_len]
                 post.step(fake_y, data.get("part") if isinstance(data, dict) else None)
         from . import ops
         ops.check_errors(dev)

@@ -124,6 +124,8 @@ struct FwdArgs {
   unsigned long long epoch;    // this launch's handshake epoch
   int* err;            // [4] sticky error words
   int B, T;
+  long p_row;          // floats between the pre-activation rows of consecutive batch rows (0: T * 4H, dense); inference over
+                       // overlapping windows (tb_lstm_fwd_windows) sets stride * 4H: P is then one row per SERIES row
   int b_begin;         // first batch row of this launch
   int rows;            // batch rows per cluster: 16 * MT, or fewer valid rows of a 16-row tile (see make_plan)
   int nclusters;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   const int u0 = u0m + sub * UE;                       // first of the UE hidden units this lane finishes
   const int b0 = a.b_begin + cl * a.rows;
   const int T = a.T;
-  const long rowP = (long)T * 4 * H, rowY = (long)T * H;
+  const long rowP = a.p_row ? a.p_row : (long)T * 4 * H, rowY = (long)T * H;
   if (tid == 0) *s_dead = 0;
   for (int i = tid; i < MT * 16 * LDH; i += 256) reinterpret_cast<unsigned*>(smem)[i] = 0u;   // hi and lo, pad included
   if (NCL > 1) {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
   // descriptors over this cluster's rows: loads of rows >= B return 0, stores to them are dropped
   int vrows = a.B - b0;
   if (vrows > a.rows) vrows = a.rows;
-  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (long)b0 * rowP), 0, (int)(vrows * rowP * 4), kBufFlags);
+  const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)(a.P + (long)b0 * rowP), 0, vrows > 0 ? (int)(((vrows - 1) * rowP + (long)T * 4 * H) * 4) : 0, kBufFlags);
   const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)((a.train ? a.cst : a.y) + (long)b0 * rowY), 0, (int)(vrows * rowY * 4), kBufFlags);
   const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)(NCL > 1 ? a.ring + (size_t)cl * 3 * RS : a.y), 0, NCL > 1 ? 3 * RS * 4 : 0, kBufFlags);
@@ -1843,14 +1845,15 @@ size_t carve(const Plan& p, int B, int H, int in_dim, bool bwd, char* base, size
 
 static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                          float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
-                         void* ws, size_t ws_bytes, int* err, void* stream, bool prof) {
+                         void* ws, size_t ws_bytes, int* err, void* stream, bool prof, long p_row = 0) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B <= 0 || T <= 0) return TB_OK;
   if (!x || !w_ih || !w_hh || !y || !ws || !err) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null pointer");
   if (reinterpret_cast<uintptr_t>(ws) & 255) return tb_set_error(TB_ERR_ARG, "lstm_fwd: the workspace must be 256-byte aligned");
   if (train && !cstash) return tb_set_error(TB_ERR_ARG, "lstm_fwd: train needs a cell stash");
   Plan p;
-  if (!make_plan(H, B, p, true, in_dim))
+  // p_row != 0: the pre-activations are given (one row per series row, windows overlap): no projection here, no fusion
+  if (!make_plan(H, B, p, true, p_row ? 0 : in_dim))
     return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: hidden size %d not supported (16,32,64,128,256,512)", H);
   // the gate buffer: projection output + BPTT stash; not touched by a fused inference launch
   if (!gates && (train || !p.XK)) return tb_set_error(TB_ERR_ARG, "lstm_fwd: null gate buffer");
@@ -1862,7 +1865,7 @@ static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, c
   // bias vectors first, then adds)
   // -- unless the layer's input is narrow enough for the recurrent kernel to do it itself (Plan::XK)
   int rc = TB_OK;
-  if (!p.XK)
+  if (!p.XK && !p_row)
     rc = tb_gemm_launch2(x, in_dim, 0, w_ih, in_dim, 0, gates, 4L * H, b_ih, b_hh, B * T, 4 * H, in_dim, 0, 0, 1,
                          nullptr, 0, s, 0);
   if (rc) return rc;
@@ -1878,6 +1881,7 @@ static int lstm_fwd_impl(const float* x, const float* w_ih, const float* w_hh, c
     a.epoch = next_epoch();
     a.err = err;
     a.B = B; a.T = T;
+    a.p_row = p_row;
     a.b_begin = c0 * p.rows_per_cluster;
     a.rows = p.rows_per_cluster;
     a.nclusters = ncl;
@@ -1922,6 +1926,21 @@ int tb_lstm_fwd(const float* x, const float* w_ih, const float* w_hh, const floa
                 float* y, float* gates, float* cstash, int B, int T, int in_dim, int H, int train,
                 void* ws, size_t ws_bytes, int* err, void* stream) {
   return lstm_fwd_impl(x, w_ih, w_hh, b_ih, b_hh, y, gates, cstash, B, T, in_dim, H, train, ws, ws_bytes, err, stream, true);
+}
+
+// Inference over OVERLAPPING windows of a series (the cleaning / prediction pass, cleaner.py:67-68 over the stride-`stride`
+// windows of dataset.py:207-212): window b's pre-activations of step t are row first_row + b * stride + t of `pseries`
+// -- x.W_ih^T + b_ih + b_hh computed ONCE per series row by the caller (tb_linear_act_fwd) instead of once per (window, step):
+// forecast_len times fewer projection flops, and the windows' encoder rows are never gathered.  Read-only on pseries.
+int tb_lstm_fwd_windows(const float* pseries, long series_rows, long first_row, long stride, const float* w_hh, float* y,
+                        int B, int T, int H, void* ws, size_t ws_bytes, int* err, void* stream) {
+  if (B <= 0 || T <= 0) return TB_OK;
+  if (!pseries || stride < 1 || first_row < 0 || first_row + (long)(B - 1) * stride + T > series_rows)
+    return tb_set_error(TB_ERR_ARG, "lstm_fwd_windows: windows leave the series");
+  if ((long)stride * 4 * H * (long)16 * 4 >= 0x7FFFFF00ll) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd_windows: stride too large");
+  // x / w_ih are not read (no projection); the gate buffer is the series projection, read-only (train = 0)
+  return lstm_fwd_impl(pseries, pseries, w_hh, nullptr, nullptr, y, const_cast<float*>(pseries) + first_row * 4 * H, nullptr, B, T,
+                       0, H, 0, ws, ws_bytes, err, stream, true, stride * 4L * H);
 }
 
 // Looks up the static scratch of the current device (tb_init calls it, so the lookup is not on a caller's

@@ -78,19 +78,34 @@ class _Loader:
         return (len(self.ws) + self.batch_size - 1) // self.batch_size
 
     def __iter__(self):
+        return self._batches(self.ws.gather)
+
+    def positions(self):
+        """The same batches WITHOUT gathering them: {"windows": (first forecast row of the first window, count, stride)}
+        (+ "part" under data parallelism) -- for consumers that read the windows in place from the device-resident
+        series (LSTMGenerator.infer_windows: the cleaning / prediction pass)."""
+        d = self.ws.ds
+
+        def where(start, count):
+            if start < 0 or count < 0 or start + count > self.ws.length:
+                raise IndexError("window range out of bounds")
+            return {"windows": (self.ws.row0 + d.observed_len + (self.ws.w0 + start) * d.stride, count, d.stride)}
+        return self._batches(where)
+
+    def _batches(self, make):
         from . import dp
         n = len(self.ws)
         for s in range(0, n, self.batch_size):
             k = min(self.batch_size, n - s)
             if self.world == 1:
-                yield self.ws.gather(s, k)
+                yield make(s, k)
                 continue
             if k < self.world:          # fewer windows than ranks: every rank runs the whole (tail) batch
-                batch = self.ws.gather(s, k)
+                batch = make(s, k)
                 batch["part"] = (0, k, True)
             else:
                 lo, hi = dp.shard(k, self.rank, self.world)
-                batch = self.ws.gather(s + lo, hi - lo)
+                batch = make(s + lo, hi - lo)
                 batch["part"] = (lo, k, False)
             yield batch
 

@@ -357,6 +357,28 @@ import os as _os
 _TWIN_SPLIT = _os.environ.get("TB_TWIN_SPLIT", "1") != "0"     # experiment knob: 0 = hidden-256 twin layers as ONE (exclusive) launch
 
 
+def lstm_fwd_windows(pseries, first_row, stride, nwin, T, w_hh):
+    """Recurrent forward (inference) of `nwin` windows of T steps whose pre-activations are rows first_row + b * stride + t
+    of the per-series-row projection `pseries` (rows, 4H): see tb_lstm_fwd_windows.  -> y (nwin, T, H)."""
+    _need_cuda(pseries, w_hh)
+    pseries, w_hh = _f32c(pseries), _f32c(w_hh.detach())
+    H = w_hh.shape[1]
+    if pseries.dim() != 2 or pseries.shape[1] != 4 * H:
+        raise RuntimeError("lstm_fwd_windows: pseries must be (rows, 4H)")
+    lib = _lib.load()
+    rt = Runtime.get(pseries.device)
+    y = torch.empty(nwin, T, H, dtype=torch.float32, device=pseries.device)
+    ws = rt.workspace(lib.tb_lstm_workspace_bytes(nwin, T, 0, H, 0))
+    excl = H > 64 and bool(lib.tb_lstm_exclusive(nwin, 0, H, 0))
+    if H > 64:
+        rt.clustered_begin(excl)
+    _lib.call("tb_lstm_fwd_windows", _ptr(pseries), pseries.shape[0], int(first_row), int(stride), _ptr(w_hh), _ptr(y),
+              nwin, T, H, _ptr(ws), ws.numel(), _ptr(rt.err), _stream())
+    if H > 64:
+        rt.clustered_end(excl)
+    return y
+
+
 def _lstm_params(lstm_module, l):
     return (getattr(lstm_module, f"weight_ih_l{l}"), getattr(lstm_module, f"weight_hh_l{l}"),
             getattr(lstm_module, f"bias_ih_l{l}"), getattr(lstm_module, f"bias_hh_l{l}"))

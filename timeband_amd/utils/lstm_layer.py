@@ -58,6 +58,31 @@ class LSTMGenerator(nn.Module):
         return out.view(B, self.outseq_len, self.out_dim)
 
 
+    def infer_windows(self, series, first, nwin, stride=1):
+        """self(windows) without a graph for the `nwin` windows whose encoder rows are series rows
+        [first + w * stride - inseq_len, first + w * stride) -- the cleaning / prediction pass (cleaner.py:67-68 over the
+        windows of dataset.py:207-212).  The windows overlap, so the first layer's input projection is computed once per
+        SERIES row and the recurrent kernel reads it in place (ops.lstm_fwd_windows): the encoder windows are never
+        gathered and the projection costs inseq_len / stride times fewer flops.  Bit-identical to self(gathered windows)."""
+        To = self.inseq_len
+        l0 = self.lstm0
+        r0 = first - To
+        nrows = (nwin - 1) * stride + To
+        if r0 < 0 or r0 + nrows > series.shape[0]:
+            raise RuntimeError("infer_windows: a window leaves the series")
+        with torch.no_grad():
+            bias = l0.bias_ih_l0 + l0.bias_hh_l0
+            pseries = ops.linear_act_raw(series[r0:r0 + nrows], l0.weight_ih_l0.detach(), bias, ops.ACT_NONE)
+            r = ops.lstm_fwd_windows(pseries, 0, stride, nwin, To, l0.weight_hh_l0)
+            for l in range(1, l0.num_layers):
+                r = ops.lstm_layer(r, *ops._lstm_params(l0, l))
+            for i in (1, 2):
+                r = ops.lstm_stack(r, getattr(self, f"lstm{i}"))
+            seq, dim = self.seq_layer[0], self.dim_layer[0]
+            s = ops.linear_act(r.view(nwin * self.hidden_dim, To), seq.weight, seq.bias, ops.ACT_NONE)
+            out = ops.linear_act(s.view(nwin * self.outseq_len, self.hidden_dim), dim.weight, dim.bias, ops.ACT_TANH)
+        return out.view(nwin, self.outseq_len, self.out_dim)
+
     def twin_joint(self, input):
         """twin() with ONE autograd graph over the 2B rows: returns (out2, fake_a, fake_b) -- out2 (2B, Tf, V) carries
         the graph; fake_a / fake_b are its two halves as detached leaves (requires_grad) for the discriminator phase and

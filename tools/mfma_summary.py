@@ -63,10 +63,10 @@ out = dict(note="rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_
                 "--kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline; bf16 MFMA flops = MOPS * 512; "
                 "every fp32-grade product is three bf16 MFMAs (useful flops = a third); peak 2.5 PFLOP/s dense bf16",
            peak_bf16_tflops=PEAK_BF16_TFLOPS, families=fam, kernels=rows)
+if len(sys.argv) > 2:
+    with open(sys.argv[2], "w") as fo:
+        json.dump(out, fo, indent=1)
 for r in rows[:20]:
     busy = "n/a" if r["mfma_busy"] is None else f"{100 * r['mfma_busy']:.1f}%"
     print(f"{r['kernel'][:70]:70s} n={r['launches']:4d} {r['avg_us']:9.1f} us  {r['bf16_tflops']:8.1f} TF bf16 "
           f"({100 * r['mfma_frac']:.1f}% of peak)  busy {busy}")
-if len(sys.argv) > 2:
-    with open(sys.argv[2], "w") as fo:
-        json.dump(out, fo, indent=1)

@@ -4,7 +4,10 @@ pass on gfx950).  Units and corrections follow MI355X_MICROARCH.md (HBM section)
 on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B per lane) coalesced reads at 64 bytes, so
 the read side is doubled for kernels whose loads are 16-byte wide (all of ours); WRITE_SIZE is exact for
 16-byte stores.
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]"""
+With a bench line (bench.py's JSON, `algo_bytes_per_launch` / `kernel_launches_per_step`) the summary also carries, per
+LSTM family, counter traffic / SURVEY 8(d) algorithmic bytes, and for the whole step the counter traffic of all three
+families against the step's algorithmic bytes (the GEMMs count as zero there: the model takes them as fused).
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json] [bench.json]"""
 import csv
 import json
 import re
@@ -52,10 +55,33 @@ out = dict(note="FETCH_SIZE doubled (gfx950 wide-read correction), KiB -> bytes;
                              read_bytes_per_launch=v[1] / max(1, v[0]), write_bytes_per_launch=v[2] / max(1, v[0]))
                      for f, v in fam.items()},
            kernels=rows)
+if len(sys.argv) > 4:
+    with open(sys.argv[4]) as fb:
+        bench = json.loads([l for l in fb.read().splitlines() if l.startswith("{")][-1])
+    algo = bench.get("algo_bytes_per_launch", {})
+    lps = bench.get("kernel_launches_per_step", {})
+    step_traffic = 0.0
+    for f, key in (("lstm_fwd_kernel", "lstm_fwd"), ("lstm_bwd_kernel", "lstm_bwd"), ("gemm", "gemm")):
+        if f in out["families"]:
+            v = out["families"][f]
+            if key in algo:
+                v["algo_bytes_per_launch"] = algo[key]
+                v["traffic_over_algorithmic"] = v["hbm_bytes_per_launch"] / algo[key]
+            if key in lps:
+                v["launches_per_step"] = lps[key]
+                step_traffic += v["hbm_bytes_per_launch"] * lps[key]
+    abw = bench.get("step_hbm_roofline", {}).get("algo_bytes_per_window")
+    gb = bench.get("config", {}).get("global_batch")
+    if abw and gb and step_traffic:
+        out["step"] = dict(counter_bytes_per_step=step_traffic, algo_bytes_per_step=abw * gb / max(1, bench.get("n_gpus", 1)),
+                           traffic_over_algorithmic=step_traffic / (abw * gb / max(1, bench.get("n_gpus", 1))))
+        print(f"step: {step_traffic / 1e9:.2f} GB counter traffic vs {out['step']['algo_bytes_per_step'] / 1e9:.2f} GB algorithmic "
+              f"= {out['step']['traffic_over_algorithmic']:.2f}x")
 for r in rows[:25]:
     print(f"{r['kernel'][:60]:60s} n={r['launches']:4d} read={r['fetch_corrected_bytes_per_launch'] / 1e6:9.2f} MB write={r['write_bytes_per_launch'] / 1e6:9.2f} MB")
 for f, v in out["families"].items():
-    print(f"family {f}: {v['launches']} launches, {v['hbm_bytes_per_launch'] / 1e6:.2f} MB/launch")
+    extra = f", {v['traffic_over_algorithmic']:.2f}x algorithmic" if "traffic_over_algorithmic" in v else ""
+    print(f"family {f}: {v['launches']} launches, {v['hbm_bytes_per_launch'] / 1e6:.2f} MB/launch{extra}")
 if len(sys.argv) > 3:
     with open(sys.argv[3], "w") as fo:
         json.dump(out, fo, indent=1)
