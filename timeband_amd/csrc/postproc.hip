@@ -315,12 +315,16 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
   const double mn = dmin ? dmin[v] : 0.0, mx = dmin ? dmax[v] : 0.0;
 #pragma unroll
   for (int f = 0; f < NP; ++f) {
+    // branch-free: every lane loads (from a clamped address where the horizon does not exist) and the value is picked
+    // afterwards -- with per-lane branches around the loads hipcc waits for each load before it issues the next one, and
+    // the forecast_len dependent gathers of an item ran one HBM latency after the other
     const int w = r - f;
-    float x = __builtin_nanf("");
-    if (f < Tf) {
-      if (w >= 0 && w < B) x = pden[((long)w * Tf + f) * V + v];
-      else if (w < 0 && -w <= nhist) x = hist[((long)(Tf - 1 + w) * Tf + f) * V + v];
-    }
+    const bool inb = f < Tf && w >= 0 && w < B;
+    const bool inh = f < Tf && w < 0 && -w <= nhist && hist != nullptr;
+    const float* src = inh ? hist : pden;
+    const long off = inb ? ((long)w * Tf + f) * V + v : (inh ? ((long)(Tf - 1 + w) * Tf + f) * V + v : (long)v);
+    float x = (B > 0 || inh) ? src[off] : 0.f;
+    x = (inb || inh) ? x : __builtin_nanf("");
     if (dmin) x = denorm1(x, mn, mx);   // NaN stays NaN
     const bool ok = !isnan(x);
     n += ok ? 1 : 0;
