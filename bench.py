@@ -200,6 +200,16 @@ def run_clean(args, cfg, device):
     abw = 4 * To * sum(i + h for i, h in ((E, H // 4), (H // 4, H // 2), (H // 2, H))) * L
     value = B * args.steps / dt
     dom = max(prof, key=lambda k: prof[k]["total_ms"])
+    # HBM bytes of one launch from the committed counter summary (profiles/r*_clean_traffic.json: tools/clean_profile.sh)
+    import glob
+    traffic = traffic_src = None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_clean_traffic.json")))
+    if files and not args.gathered:
+        try:
+            with open(files[-1]) as f:
+                traffic, traffic_src = round(json.load(f)["hbm_bytes_per_step"], 1), os.path.basename(files[-1])
+        except Exception:
+            pass
     out = {"metric": "cleaning windows/sec", "value": round(value, 1), "unit": "windows/s", "n_gpus": 1, "rccl_ranks": 0,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -209,7 +219,8 @@ def run_clean(args, cfg, device):
                       "series_rows": N, "windows": len(full), "dataset_setup_s": round(setup_s, 2)},
            "roofline": {"bound": "hbm", "kernel": "whole cleaning launch (all kernels of one step)",
                         "achieved": round(abw * value / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(abw * value / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(abw * value / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                        "traffic_note": "per launch of B windows, all kernels of the step",
                         "algo_bytes_per_window": abw, "dominant_family": dom},
            "kernel_ms_per_step": {k: round(v["total_ms"] / max(1, extra), 4) for k, v in prof.items()}}
     print(json.dumps(out), flush=True)

@@ -43,12 +43,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.tb_loss_workspace_bytes() > 0
 
 
+def test_cpp_extension_loads_and_exposes_its_ops():
+    """timeband_amd/_tbext.so (csrc/ext.cpp: the PyTorch-ROCm C++ extension over the C-ABI) imports without a GPU and
+    carries the autograd entry points ops.py routes through; a CPU tensor is refused, not computed."""
+    import torch
+    from timeband_amd import ops
+    ext = ops._load_ext()
+    assert ext is not None, "build the extension first: python -m timeband_amd.build"
+    for name in ("lstm_layer", "lstm_fwd_raw", "linear_act", "linear_act_raw", "set_runtime", "clustered_begin",
+                 "clustered_end", "set_grads_hook", "arm_grads_hook"):
+        assert hasattr(ext, name), name
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ext.linear_act_raw(torch.zeros(4, 8), torch.zeros(3, 8), None, 0)
+
+
 def test_product_path_has_no_oracle_import():
     """Nothing under timeband_amd/ may import, call or link anything under oracle/."""
     pkg = os.path.join(ROOT, "timeband_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h")):
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "timeband_oracle" not in src and "torch_cpu_port" not in src, f

@@ -71,7 +71,11 @@ class LSTMGenerator(nn.Module):
         if r0 < 0 or r0 + nrows > series.shape[0]:
             raise RuntimeError("infer_windows: a window leaves the series")
         with torch.no_grad():
-            bias = l0.bias_ih_l0 + l0.bias_hh_l0
+            # b_ih + b_hh, summed first like the projection GEMM's two-bias epilogue; cached until a parameter changes
+            key = (l0.bias_ih_l0._version, l0.bias_hh_l0._version, l0.bias_ih_l0.data_ptr())
+            if getattr(self, "_bias0", (None, None))[0] != key:
+                self._bias0 = (key, (l0.bias_ih_l0 + l0.bias_hh_l0).detach())
+            bias = self._bias0[1]
             pseries = ops.linear_act_raw(series[r0:r0 + nrows], l0.weight_ih_l0.detach(), bias, ops.ACT_NONE)
             r = ops.lstm_fwd_windows(pseries, 0, stride, nwin, To, l0.weight_hh_l0)
             for l in range(1, l0.num_layers):
