@@ -105,6 +105,9 @@ int static_scratch(void** out) {
   return TB_OK;
 }
 
+#ifndef TB_POLL_ABOVE
+#define TB_POLL_ABOVE 8      // clusters of more members poll one piece per producer before they pull (A/B knob)
+#endif
 constexpr unsigned kSentinel = 0xFFFFFFFFu;   // all-ones: a NaN pattern no computed h equals
 constexpr int kBufFlags = 0x00020000;         // raw buffer descriptor word 3 (32-bit raw, bounds-checked)
 constexpr int kSC1 = 16;                      // aux: sc1 = write-through store / L1-bypassing load
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       // to the allocator, half of them are spilled to accumulation registers and copied back in front of every MFMA
       // (4 v_accvgpr_read per use, all through one temporary); pinned there as values of the AGPR class, the MFMAs
       // read them in place.
-      if (EMU2) asm volatile("" : "+a"(wlo[g][s]));
+      if (EMU2 || (H == 512 && US == 32)) asm volatile("" : "+a"(wlo[g][s]));   // the 16-member layout of hidden 512 holds the same 256 registers
     }
   // W_ih fragments: in LDS for the clustered variants (no registers to spare: two of their launches must fit a CU),
   // in registers like W_hh for single-workgroup layers (re-reading them every step would put 40-80 KB per step
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
         // stored after the pull.
         // Clusters of more than 8 members (hidden 512: 32 members) keep the poll: with that many producers per wave the
         // first pull mostly comes back armed and the re-pull loop hammers the ring (5.06 against 4.52 us/step without it).
-        constexpr bool POLL = NCL > 8;
+        constexpr bool POLL = NCL > (TB_POLL_ABOVE);
         if (POLL && MT == 1 && lane < NPP * NUG) {
           const int m = wave + (lane / NUG) * NPW;
           if (m < NCL && m != j) {
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       tb_split8(v0, v1, wbh[nt][s], wbl[nt][s]);
       // 4-member layout (256 registers of fragments): the lo halves live in accumulation registers, where the MFMAs read
       // them in place (left to the allocator they are spilled there and copied back in front of every use)
-      if (H == 256 && US == 64) asm volatile("" : "+a"(wbl[nt][s]));
+      if ((H == 256 && US == 64) || (H == 512 && US == 32)) asm volatile("" : "+a"(wbl[nt][s]));
     }
   // elementwise items: e = tid + 256*n -> unit group qd (constant per thread) of UI units, row, mt
   // (f32x4 containers, the first UI elements in use)
@@ -1360,7 +1363,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     // Clusters of more than 8 members (hidden 512: 32) keep the poll of one piece per producer by one wave, and the
     // barrier that hands its result to the others: every thread pulling 32 mostly armed pieces over and over costs far
     // more than the round trip saved (6.19 against 3.83 us/step).
-    constexpr bool POLL = NCL > 8;
+    constexpr bool POLL = NCL > (TB_POLL_ABOVE);
     if constexpr (POLL) {
       if (wave == 0 && lane < NCL && lane != j) {
         const int voff = (int)(((long)par * XSLAB + ((long)(j * NCL + lane) * MT * 16 + MT * 16 - 1) * US + US - 4) * 4);
@@ -1640,6 +1643,12 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   // clustered launch in flight (the Python host orders it: ops.Runtime.clustered_begin).  TB_WIDE256=0 turns it off.
   static const bool wide256 = []() { const char* e = getenv("TB_WIDE256"); return !e || atoi(e) != 0; }();
   if (H == 256 && wide256 && B > 16 * (tb_num_cus() / 8)) { US = 64; KS = 1; }
+  // Hidden 512: 16-member clusters (32 units per member, two k-part waves per unit group, W_hh on 256 registers like the
+  // 4-member layout of hidden 256) instead of 32 members of 16 units: half the exchange fan-in, twice the clusters per
+  // launch.  For EVERY batch size -- the k split decides the summation order, and a window's result must not depend
+  // on the batch it sits in.  ~390 registers per lane: such a launch is EXCLUSIVE as well.  TB_WIDE512=0 turns it off.
+  static const bool wide512 = []() { const char* e = getenv("TB_WIDE512"); return !e || atoi(e) != 0; }();
+  if (H == 512 && wide512) { US = 32; KS = 2; }
   p.H = H; p.US = US; p.KS = KS; p.NCL = H / US;
   const int XK = fwd ? fused_xk(H, in_dim) : 0;
   p.XK = XK;
@@ -1651,7 +1660,7 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   // the variants that can meet on a full-size batch stay within half a SIMD's registers (256), so two such
   // launches always fit side by side.  BPTT at H=256 with two tiles needs 288 and is no faster than two
   // one-tile launches (6.0 vs 2 x 2.9 us/step), hence the cap of 1 there.
-  const int mt_cap = US == 64 && H == 256 ? 1 : (fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4)));
+  const int mt_cap = ((US == 64 && H == 256) || (US == 32 && H == 512)) ? 1 : (fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4)));
   const int NUG = US / 16;
   const int HK = H < 32 ? 32 : H;
   const int NCL = p.NCL;
@@ -1745,6 +1754,7 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   if (p.US == 64) { FWD_CASE32(256, 64, 1, 1); }
   FWD_CASE32(256, 32, 2, 1); FWD_CASE32(256, 32, 2, 2);
+  if (p.US == 32) { FWD_CASE0(512, 32, 2, 1); }
   FWD_CASE0(512, 16, 4, 1); FWD_CASE0(512, 16, 4, 2);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }
@@ -1781,6 +1791,7 @@ int launch_bwd(const Plan& p, const BwdArgs& a, int grid, hipStream_t s) {
   BWD_CASE(128, 32, 1); BWD_CASE(128, 32, 2); BWD_CASE(128, 32, 4);
   if (p.US == 64) { BWD_CASE(256, 64, 1); }
   BWD_CASE(256, 32, 1); BWD_CASE(256, 32, 2);
+  if (p.US == 32) { BWD_CASE(512, 32, 1); }
   BWD_CASE(512, 16, 1);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }
@@ -1914,7 +1925,7 @@ size_t tb_lstm_workspace_bytes(int B, int T, int in_dim, int H, int backward) {
 int tb_lstm_exclusive(int B, int in_dim, int H, int backward) {
   Plan p;
   if (!make_plan(H, B, p, backward == 0, in_dim)) return 0;
-  return (p.H == 256 && p.US == 64) ? 1 : 0;
+  return ((p.H == 256 && p.US == 64) || (p.H == 512 && p.US == 32)) ? 1 : 0;
 }
 
 int tb_lstm_supported(int H) {
@@ -2016,7 +2027,7 @@ static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, con
   if (need > ws_bytes) return tb_set_error(TB_ERR_WORKSPACE, "lstm_bwd: workspace %zu < %zu", ws_bytes, need);
   // input gradient inside the kernel (see dx_in_kernel): only when somebody wants it, and within the co-residency rule
   const bool want_dx = dx && dx_row_begin < B;
-  const bool excl = p.H == 256 && p.US == 64;
+  const bool excl = (p.H == 256 && p.US == 64) || (p.H == 512 && p.US == 32);
   const bool dxk = want_dx && c.dxpart && (excl || p.lds_bwd + dx_extra_lds(p) <= 80 * 1024);
   if (!tile_fits_descriptor(p, T, H)) return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_bwd: T*H too large (%d x %d)", T, H);
   const int ncl_total = (B + p.rows_per_cluster - 1) / p.rows_per_cluster;
