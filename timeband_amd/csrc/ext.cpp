@@ -9,8 +9,8 @@
 #include <torch/extension.h>
 
 #include <c10/hip/HIPStream.h>
-#include <ATen/hip/HIPEvent.h>
-#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPException.h>
+#include <hip/hip_runtime_api.h>
 
 #include <algorithm>
 #include <atomic>
@@ -44,8 +44,8 @@ Tensor f32c(const Tensor& t, const char* what) {
 // co-residency guard of the clustered recurrent launches (see ops.Runtime.clustered_begin for the rule) -------------
 struct Clustered {
   uint64_t seq;
-  std::shared_ptr<at::cuda::CUDAEvent> ev;
   bool excl;
+  c10::hip::HIPStream stream;
 };
 struct Rt {
   Tensor err;
@@ -80,33 +80,55 @@ int* err_ptr(int dev) {
   return rt_of(dev).err.data_ptr<int>();
 }
 
+// The guard WITHOUT an event per launch (the Python guard records one behind every clustered launch: ~16 per iteration,
+// each a marker packet between two dependent kernels).  A stream's entry only remembers the order and kind of its last
+// clustered launch; an event is recorded -- at that stream's TAIL, i.e. behind whatever was queued there since: a later
+// point than the launch itself, so waiting for it is conservative, never too little -- only when another stream really
+// has to wait: the third stream with a launch in flight, or either side of an exclusive launch.  With the default
+// schedule (one side stream; the exclusive launches run while the other stream has been joined) no event is recorded
+// at all.  A stream with nothing left to do (hipStreamQuery) drops out.
+void wait_for_tail(c10::hip::HIPStream& other, c10::hip::HIPStream& cur) {
+  hipEvent_t ev;
+  C10_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  C10_HIP_CHECK(hipEventRecord(ev, other.stream()));
+  C10_HIP_CHECK(hipStreamWaitEvent(cur.stream(), ev, 0));
+  C10_HIP_CHECK(hipEventDestroy(ev));      // released once it has completed
+}
+
 void clustered_begin(int dev, bool exclusive) {
   std::lock_guard<std::mutex> lk(g_mu);
   Rt& rt = rt_of(dev);
   if (rt.clustered.empty()) return;
-  auto cur = at::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)dev);
+  auto cur = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
   void* key = (void*)cur.stream();
-  std::vector<std::pair<uint64_t, std::shared_ptr<at::cuda::CUDAEvent>>> live;
+  // hipStreamQuery costs tens of microseconds on a busy stream: asked only where a wait would otherwise be queued
+  std::vector<void*> live;
   for (auto it = rt.clustered.begin(); it != rt.clustered.end();) {
     if (it->first == key) { ++it; continue; }
-    if (it->second.ev->query()) { it = rt.clustered.erase(it); continue; }
-    if (it->second.excl || exclusive) it->second.ev->block(cur);
-    else live.emplace_back(it->second.seq, it->second.ev);
+    if (it->second.excl || exclusive) {
+      if (it->second.stream.query()) { it = rt.clustered.erase(it); continue; }
+      wait_for_tail(it->second.stream, cur);
+    } else live.push_back(it->first);
     ++it;
   }
-  std::sort(live.begin(), live.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
-  for (size_t i = 0; i + 1 < live.size(); ++i) live[i].second->block(cur);
+  if (live.size() > 1) {
+    std::sort(live.begin(), live.end(), [&](void* a, void* b) { return rt.clustered.at(a).seq < rt.clustered.at(b).seq; });
+    for (size_t i = 0; i + 1 < live.size(); ++i) {
+      Clustered& c = rt.clustered.at(live[i]);
+      if (c.stream.query()) rt.clustered.erase(live[i]);
+      else wait_for_tail(c.stream, cur);
+    }
+  }
 }
 
 void clustered_end(int dev, bool exclusive) {
   std::lock_guard<std::mutex> lk(g_mu);
   Rt& rt = rt_of(dev);
-  auto cur = at::hip::getCurrentHIPStreamMasqueradingAsCUDA((c10::DeviceIndex)dev);
+  auto cur = c10::hip::getCurrentHIPStream((c10::DeviceIndex)dev);
   void* key = (void*)cur.stream();
   auto it = rt.clustered.find(key);
-  std::shared_ptr<at::cuda::CUDAEvent> ev = it != rt.clustered.end() ? it->second.ev : std::make_shared<at::cuda::CUDAEvent>();
-  ev->record(cur);
-  rt.clustered[key] = Clustered{++rt.seq, ev, exclusive};
+  if (it == rt.clustered.end()) rt.clustered.emplace(key, Clustered{++rt.seq, exclusive, cur});
+  else { it->second.seq = ++rt.seq; it->second.excl = exclusive; }
 }
 
 void set_runtime(int dev, Tensor err) {
@@ -174,7 +196,7 @@ struct LSTMLayerFn : public torch::autograd::Function<LSTMLayerFn> {
                         int64_t dx_from, int64_t split, OptT s_wih, OptT s_whh, OptT s_bih, OptT s_bhh, OptT pre_y,
                         OptT pre_gates, OptT pre_cst) {
     Tensor xc = f32c(x, "x"), wi = f32c(w_ih, "w_ih"), wh = f32c(w_hh, "w_hh");
-    const int64_t B = xc.size(0), T = xc.size(1), In = xc.size(2), H = wh.size(1);
+    const int64_t B = xc.size(0), T = xc.size(1), H = wh.size(1);
     Tensor y, gates, cst;
     if (pre_y.has_value()) {
       y = pre_y->alias();
