@@ -1660,7 +1660,10 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   // the variants that can meet on a full-size batch stay within half a SIMD's registers (256), so two such
   // launches always fit side by side.  BPTT at H=256 with two tiles needs 288 and is no faster than two
   // one-tile launches (6.0 vs 2 x 2.9 us/step), hence the cap of 1 there.
-  const int mt_cap = ((US == 64 && H == 256) || (US == 32 && H == 512)) ? 1 : (fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4)));
+  // two interleaved tiles per cluster in the forward pass: 127.6 against 130.5 ms per cfg4 step (BPTT with two tiles: 112
+  // against 102 ms, not built in)
+  static const int mt512 = []() { const char* e = getenv("TB_MT512"); return e ? atoi(e) : 2; }();
+  const int mt_cap = (US == 64 && H == 256) ? 1 : (US == 32 && H == 512) ? (fwd ? mt512 : 1) : (fwd ? ((H >= 256 || H == 64) ? 2 : 4) : ((H >= 256) ? 1 : (H == 64 ? 2 : 4)));
   const int NUG = US / 16;
   const int HK = H < 32 ? 32 : H;
   const int NCL = p.NCL;
@@ -1675,7 +1678,8 @@ bool make_plan(int H, int B, Plan& p, bool fwd = false, int in_dim = 0) {
   auto lds_b = [=](int mt) { return ((size_t)mt * 16 * (4 * US + 8) + (size_t)mt * 16 * (H + 4) + 4096) * 4 + 16; };
   // ... and within half a CU's LDS (80 KiB): a clustered variant leaves room for a second clustered workgroup
   constexpr size_t kLdsHalf = 80 * 1024;
-  auto fits = [=](int mt) { return NCL == 1 || (fwd ? lds_f(mt) : lds_b(mt)) <= kLdsHalf; };
+  const size_t lds_cap = (US == 32 && H == 512) ? 2 * kLdsHalf - 1024 : kLdsHalf;   // an exclusive launch has the CU to itself
+  auto fits = [=](int mt) { return NCL == 1 || (fwd ? lds_f(mt) : lds_b(mt)) <= lds_cap; };
   while (MT < mt_cap && (B + 16 * MT - 1) / (16 * MT) > max_clusters && fits(2 * MT)) MT *= 2;
   p.MT = MT;
   // Fewer VALID rows per 16-row MFMA tile when the batch has far fewer tiles than the chip has clusters (hidden 64
@@ -1754,7 +1758,7 @@ int launch_fwd(const Plan& p, const FwdArgs& a, int grid, hipStream_t s) {
   FWD_CASE(128, 32, 2, 1); FWD_CASE(128, 32, 2, 2); FWD_CASE(128, 32, 2, 4);
   if (p.US == 64) { FWD_CASE32(256, 64, 1, 1); }
   FWD_CASE32(256, 32, 2, 1); FWD_CASE32(256, 32, 2, 2);
-  if (p.US == 32) { FWD_CASE0(512, 32, 2, 1); }
+  if (p.US == 32) { FWD_CASE0(512, 32, 2, 1); FWD_CASE0(512, 32, 2, 2); }
   FWD_CASE0(512, 16, 4, 1); FWD_CASE0(512, 16, 4, 2);
   return tb_set_error(TB_ERR_UNSUPPORTED, "lstm_fwd: no kernel for H=%d MT=%d", p.H, p.MT);
 }

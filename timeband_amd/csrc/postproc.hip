@@ -281,40 +281,50 @@ __global__ __launch_bounds__(64 * BAND_WAVES) void band_kernel(const float* __re
 // horizons and NaNs become +inf and sort to the end, so the first n sorted entries are the valid ones).
 constexpr int BAND_T_MAX = 64;    // 128 values per thread no longer fit the register file
 
-template <int NP>
-__device__ __forceinline__ void bitonic_sort(float (&a)[NP]) {
+// Batcher's odd-even merge sort over P slots (a power of two) of which only the first NS exist: the missing ones stand
+// for +inf, which a (low index <- min, high index <- max) comparator never moves, so every comparator that touches a
+// slot >= NS is dropped (NS = 48: 384 comparators against 672 of a 64-wide bitonic network).  Fully unrolled: the
+// values stay in registers.
+template <int NS>
+__device__ __forceinline__ void network_sort(float (&a)[NS]) {
+  constexpr int P = NS <= 8 ? 8 : (NS <= 16 ? 16 : (NS <= 32 ? 32 : 64));
 #pragma unroll
-  for (int k = 2; k <= NP; k <<= 1) {
+  for (int p = 1; p < P; p <<= 1) {
 #pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
+    for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const int l = i ^ j;
-        if (l > i) {
-          const float lo = fminf(a[i], a[l]), hi = fmaxf(a[i], a[l]);
-          const bool up = (i & k) == 0;
-          a[i] = up ? lo : hi;
-          a[l] = up ? hi : lo;
+      for (int j = k % p; j <= P - 1 - k; j += 2 * k) {
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+          const int x = i + j, y = i + j + k;
+          if (y < NS && x / (2 * p) == y / (2 * p)) {
+            const float lo = fminf(a[x], a[y]), hi = fmaxf(a[x], a[y]);
+            a[x] = lo;
+            a[y] = hi;
+          }
         }
       }
     }
   }
 }
 
-template <int NP>
+// Rows below `direct_rows` (those the std smear does not touch) get their band written here; band_finish_kernel does the rest.
+template <int NS>
 __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V, int nrows,
                                                         const float* __restrict__ hist, int nhist,
                                                         const double* __restrict__ dmin, const double* __restrict__ dmax,
-                                                        double* __restrict__ med, double* __restrict__ sd) {
+                                                        double* __restrict__ med, double* __restrict__ sd,
+                                                        int direct_rows, double width, double* __restrict__ lower,
+                                                        double* __restrict__ upper) {
   const long item = (long)blockIdx.x * 256 + threadIdx.x;
   const long nitems = (long)nrows * V;
   if (item >= nitems) return;
   const int r = (int)(item / V), v = (int)(item % V);
-  float a[NP];
+  float a[NS];
   int n = 0;
   const double mn = dmin ? dmin[v] : 0.0, mx = dmin ? dmax[v] : 0.0;
 #pragma unroll
-  for (int f = 0; f < NP; ++f) {
+  for (int f = 0; f < NS; ++f) {
     // branch-free: every lane loads (from a clamped address where the horizon does not exist) and the value is picked
     // afterwards -- with per-lane branches around the loads hipcc waits for each load before it issues the next one, and
     // the forecast_len dependent gathers of an item ran one HBM latency after the other
@@ -330,30 +340,38 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
     n += ok ? 1 : 0;
     a[f] = ok ? x : __builtin_inff();
   }
+  double m_out, s_out;
   if (n == 0) {
-    med[item] = __builtin_nan("");
-    sd[item] = __builtin_nan("");
-    return;
-  }
-  bitonic_sort<NP>(a);
-  const int lo = (n - 1) >> 1, hi = n >> 1;
-  float mlo = 0.f, mhi = 0.f;
-  double s = 0.0;
+    m_out = __builtin_nan("");
+    s_out = __builtin_nan("");
+  } else {
+    network_sort<NS>(a);
+    const int lo = (n - 1) >> 1, hi = n >> 1;
+    float mlo = 0.f, mhi = 0.f;
+    double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    if (i == lo) mlo = a[i];
-    if (i == hi) mhi = a[i];
-    s += i < n ? (double)a[i] : 0.0;
-  }
-  const double mean = s / (double)n;
-  double q = 0.0;
+    for (int i = 0; i < NS; ++i) {
+      if (i == lo) mlo = a[i];
+      if (i == hi) mhi = a[i];
+      s += i < n ? (double)a[i] : 0.0;
+    }
+    const double mean = s / (double)n;
+    double q = 0.0;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const double d = (double)a[i] - mean;
-    q += i < n ? d * d : 0.0;
+    for (int i = 0; i < NS; ++i) {
+      const double d = (double)a[i] - mean;
+      q += i < n ? d * d : 0.0;
+    }
+    m_out = lo == hi ? (double)mlo : ((double)mlo + (double)mhi) / 2.0;   // np.median: mean of the two middle values
+    s_out = sqrt(q / (double)n);
   }
-  med[item] = lo == hi ? (double)mlo : ((double)mlo + (double)mhi) / 2.0;   // np.median: mean of the two middle values
-  sd[item] = sqrt(q / (double)n);
+  med[item] = m_out;
+  sd[item] = s_out;
+  if (r < direct_rows) {
+    const double w = width * s_out;
+    lower[item] = m_out - w;
+    upper[item] = m_out + w;
+  }
 }
 
 // std smear over the last Tf rows (trainer.py:280-282): a chain along the rows, one thread per variable
@@ -368,9 +386,9 @@ __global__ void band_smear_kernel(double* __restrict__ sd, int R, int Tf, int V)
 }
 
 // ... then the band, elementwise
-__global__ void band_finish_kernel(const double* __restrict__ med, const double* __restrict__ sd, long n, double width,
+__global__ void band_finish_kernel(const double* __restrict__ med, const double* __restrict__ sd, long first, long n, double width,
                                    double* __restrict__ lower, double* __restrict__ upper) {
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  for (long i = first + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const double m = med[i], w = width * sd[i];
     lower[i] = m - w;
     upper[i] = m + w;
@@ -650,11 +668,18 @@ int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hi
   const size_t lds = (size_t)BAND_WAVES * Tf * sizeof(float);
   if (lds > 60 * 1024) return tb_set_error(TB_ERR_UNSUPPORTED, "band_update: forecast_len %d too long", Tf);
   tb_prof_begin(TB_K_BAND, s);
+  int direct_rows = 0;   // rows whose band the sort kernel writes itself (the smear changes the std of the last Tf rows only)
   if (Tf <= BAND_T_MAX) {
     const dim3 g((unsigned)((nitems + 255) / 256));
-    if (Tf <= 16) hipLaunchKernelGGL(band_sort_kernel<16>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
-    else if (Tf <= 32) hipLaunchKernelGGL(band_sort_kernel<32>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
-    else hipLaunchKernelGGL(band_sort_kernel<64>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
+    direct_rows = smear ? (R - Tf > 0 ? R - Tf : 0) : rows_out;
+#define TB_BAND_CASE(ns)                                                                                                  \
+  if (Tf <= ns) {                                                                                                          \
+    hipLaunchKernelGGL(band_sort_kernel<ns>, g, dim3(256), 0, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, \
+                       sd, direct_rows, band_width, lower, upper);                                                          \
+  } else
+    TB_BAND_CASE(8) TB_BAND_CASE(16) TB_BAND_CASE(24) TB_BAND_CASE(32) TB_BAND_CASE(40) TB_BAND_CASE(48) TB_BAND_CASE(56)
+    TB_BAND_CASE(64) {}
+#undef TB_BAND_CASE
     TB_LAUNCH_CHECK("band_sort_kernel");
   } else {
     hipLaunchKernelGGL(band_kernel, dim3((unsigned)((nitems + BAND_WAVES - 1) / BAND_WAVES)), dim3(64 * BAND_WAVES),
@@ -665,9 +690,12 @@ int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hi
     hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
     TB_LAUNCH_CHECK("band_smear_kernel");
   }
-  hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems)), dim3(256), 0, s, med, sd, nitems, band_width, lower,
-                     upper);
-  TB_LAUNCH_CHECK("band_finish_kernel");
+  if (direct_rows < rows_out) {
+    const long first = (long)direct_rows * V;
+    hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems - first)), dim3(256), 0, s, med, sd, first, nitems, band_width,
+                       lower, upper);
+    TB_LAUNCH_CHECK("band_finish_kernel");
+  }
   if (hist_out) {
     hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for((long)(Tf - 1) * Tf * V)), dim3(256), 0, s, pden, B, Tf, V,
                        hist_in, hist_out);

@@ -1,9 +1,6 @@
 set -o pipefail
-cd /tmp && export TMPDIR=/tmp
-out=$GRAFT_REPO_ROOT/gpurun_out/tl1; mkdir -p $out
-cd $GRAFT_REPO_ROOT
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $out/tr -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline > $out/log.txt 2>&1 || { tail -20 $out/log.txt; exit 1; }
-f=$(find $out/tr -name '*kernel_trace.csv' | head -1)
-python tools/trace_timeline.py $f > $out/timeline.txt
-tail -60 $out/timeline.txt
-rm -rf $out/tr
+mkdir -p gpurun_out/c45e
+timeout -k 10 300 python -u -m pytest tests/test_gpu_kernels.py tests/test_gpu_pipeline.py tests/test_gpu_dp.py -m gpu -x -q -k "band or pipeline or clean or world1" --timeout 300 --timeout-method thread 2>&1 | tail -3 || exit 1
+timeout -k 10 300 python bench.py --config cfg5 --rows 10000000 --steps 1220 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/c45e/cfg5.json || exit 1
+python -c "
+import json; d=json.load(open('gpurun_out/c45e/cfg5.json')); print('cfg5', d['ms_per_step'], d['value'], d['roofline']['frac'], d.get('kernel_ms_per_step'))"
