@@ -66,7 +66,9 @@ def pmc_traffic(family):
     (profiles/r*_traffic.json, made by tools/gpu_profile.sh + tools/pmc_summary.py from separate
     FETCH_SIZE / WRITE_SIZE passes of this same command; counters cannot be read inside this process)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))
+                   if re.fullmatch(r"r\d+_traffic\.json", os.path.basename(f)))   # not the per-config ones (r03_cfg4_..., r03_clean_...)
     if not files:
         return None, None
     try:
@@ -81,7 +83,9 @@ def pmc_mfma():
     """bf16 MFMA issue rate of the GEMM family from the latest committed counter summary (profiles/r*_mfma.json:
     tools/gpu_profile.sh's SQ_INSTS_VALU_MFMA_MOPS_BF16 pass of this same command + tools/mfma_summary.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_mfma.json"))
+                   if re.fullmatch(r"r\d+_mfma\.json", os.path.basename(f)))
     if not files:
         return None
     try:

@@ -20,6 +20,6 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format cs
 # MFMA utilisation (row d-2): 3 SQ counters + 1 GRBM counter, a pass of its own
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_mfma.log" 2>&1 || { tail -30 "$out/pmc_mfma.log"; exit 1; }
 python tools/pmc_summary.py "$(find "$out/pmc_fetch" -name '*counter_collection.csv' | head -1)" "$(find "$out/pmc_write" -name '*counter_collection.csv' | head -1)" "$out/${rnd}_traffic.json" "$out/${rnd}_bench.json" | tail -12
-python tools/mfma_summary.py "$(find "$out/pmc_mfma" -name '*counter_collection.csv' | head -1)" "$out/${rnd}_mfma.json" | head -12
+python tools/mfma_summary.py "$(find "$out/pmc_mfma" -name '*counter_collection.csv' | head -1)" "$out/${rnd}_mfma.json" > "$out/mfma.txt"; sed -n 1,12p "$out/mfma.txt"
 rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_mfma"
 tail -1 "$out/bench.log"

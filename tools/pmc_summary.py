@@ -74,7 +74,10 @@ if len(sys.argv) > 4:
     gb = bench.get("config", {}).get("global_batch")
     if abw and gb and step_traffic:
         out["step"] = dict(counter_bytes_per_step=step_traffic, algo_bytes_per_step=abw * gb / max(1, bench.get("n_gpus", 1)),
-                           traffic_over_algorithmic=step_traffic / (abw * gb / max(1, bench.get("n_gpus", 1))))
+                           traffic_over_algorithmic=step_traffic / (abw * gb / max(1, bench.get("n_gpus", 1))),
+                           note="SURVEY 8(d)'s per-window figure leaves the critic step out (forecast_len windows per iteration: "
+                                "128 beside a batch of 512 at cfg2; 1024 beside a batch of 64 at cfg4, where this ratio "
+                                "therefore says nothing -- use the per-family ratios)")
         print(f"step: {step_traffic / 1e9:.2f} GB counter traffic vs {out['step']['algo_bytes_per_step'] / 1e9:.2f} GB algorithmic "
               f"= {out['step']['traffic_over_algorithmic']:.2f}x")
 for r in rows[:25]:
