@@ -169,10 +169,13 @@ int tb_rmsprop_step(float* p, const float* g, float* sq, long n, double lr, doub
 /* Gradient-buffer housekeeping on the caller's stream (no counterpart in the reference's source: these are what
  * torch does inside optimizer.zero_grad() / autograd's accumulation, source/trainer.py:151,160-161,179,193, and
  * torch.cat).  tb_zero: bytes <- 0.  tb_grad_merge: g[i] += g2[i]; g2[i] = 0 (two backward passes of one network that
- * ran side by side into two buffers; 16-byte aligned).  tb_concat2: out = a followed by b (device-to-device copies). */
+ * ran side by side into two buffers; 16-byte aligned).  tb_concat2: out = a followed by b (device-to-device copies).
+ * tb_concat2_sum: out = a (na floats) followed by b + b2 (nb floats), one launch: a leaf that two losses reach gets its two
+ * gradient contributions in two buffers, and their sum is formed while the joint upstream gradient is assembled. */
 int tb_zero(void* p, size_t bytes, void* stream);
 int tb_grad_merge(float* g, float* g2, long n, void* stream);
 int tb_concat2(const void* a, size_t bytes_a, const void* b, size_t bytes_b, void* out, void* stream);
+int tb_concat2_sum(const float* a, long na, const float* b, const float* b2, long nb, float* out, void* stream);
 
 /* ---- data side ------------------------------------------------------------------------------------
  * tb_window_gather: windows of the normalised series (source/dataset.py:199-214 + utils/dataset.py:17-23):

@@ -538,3 +538,25 @@ def test_lstm_single_step_single_row(dev):
         else:
             assert float(ts[2].grad.abs().max()) == 0.0          # h_{-1} = 0: no gradient reaches W_hh
         assert rel(ts[3].grad.cpu().numpy(), dbi_ref) < 1e-4
+
+
+def test_gradient_housekeeping_ops(dev):
+    """tb_zero / tb_grad_merge / tb_concat2 / tb_concat2_sum against torch (exact: copies and single fp32 additions)."""
+    from timeband_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for rows, tail in ((64, (24, 8)), (5, (3, 7)), (1, (1,))):      # 16-byte multiples and ragged sizes
+        a = torch.randn((rows,) + tail, generator=g).to(dev)
+        b = torch.randn((rows + 2,) + tail, generator=g).to(dev)
+        b2 = torch.randn((rows + 2,) + tail, generator=g).to(dev)
+        assert torch.equal(ops.concat2(a, b), torch.cat([a, b], 0))
+        assert torch.equal(ops.concat2(a, b, b2), torch.cat([a, b + b2], 0))
+        assert torch.equal(ops.concat2(a[:0], b, b2), b + b2)
+    with pytest.raises(RuntimeError):
+        ops.concat2(a, b, b2[:1])
+    n = 4 * 1000 + 3
+    x, y = torch.randn(n, generator=g).to(dev), torch.randn(n, generator=g).to(dev)
+    want = x + y
+    ops.grad_merge(x, y)
+    assert torch.equal(x, want) and not y.any()
+    ops.zero_(x)
+    assert not x.any()

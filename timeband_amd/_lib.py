@@ -62,6 +62,7 @@ SIGNATURES = {
     "tb_zero": (I, [P, Z, P]),
     "tb_grad_merge": (I, [P, P, L, P]),
     "tb_concat2": (I, [P, Z, P, Z, P, P]),
+    "tb_concat2_sum": (I, [P, L, P, P, L, P, P]),
     "tb_interpolate_workspace_bytes": (Z, [L, I]),
     "tb_interpolate": (I, [P, L, I, P, I, L, P, P, Z, P]),
     "tb_minmax_workspace_bytes": (Z, [I]),

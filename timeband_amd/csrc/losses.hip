@@ -471,6 +471,22 @@ __global__ void grad_merge_kernel(float* __restrict__ g, float* __restrict__ g2,
     g2[i] = 0.f;
   }
 }
+// out = [a ; b + b2] (floats): the upstream gradient of the joint generator backward -- the discriminator phase's dfake, then
+// the generator phase's two contributions (reconstruction / gradient-penalty terms and the path through D), summed on the way
+__global__ void concat2_sum_kernel(const float* __restrict__ a, long na, const float* __restrict__ b, const float* __restrict__ b2,
+                                   long nb, float* __restrict__ out, int vec) {
+  const long stride = (long)gridDim.x * blockDim.x, i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const long na4 = na / 4, nb4 = nb / 4;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    const f32x4* c4 = reinterpret_cast<const f32x4*>(b2);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long i = i0; i < na4 + nb4; i += stride) o4[i] = i < na4 ? a4[i] : b4[i - na4] + c4[i - na4];
+  } else {
+    for (long i = i0; i < na + nb; i += stride) out[i] = i < na ? a[i] : b[i - na] + b2[i - na];
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -499,6 +515,19 @@ int tb_concat2(const void* a, size_t bytes_a, const void* b, size_t bytes_b, voi
     if (rc) return rc;
   }
   if (bytes_b) return tb_check_hip(hipMemcpyAsync(static_cast<char*>(out) + bytes_a, b, bytes_b, hipMemcpyDeviceToDevice, s), "concat2");
+  return TB_OK;
+}
+
+int tb_concat2_sum(const float* a, long na, const float* b, const float* b2, long nb, float* out, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (na < 0 || nb < 0) return tb_set_error(TB_ERR_ARG, "concat2_sum: negative length");
+  if (na + nb == 0) return TB_OK;
+  if ((na && !a) || (nb && (!b || !b2)) || !out) return tb_set_error(TB_ERR_ARG, "concat2_sum: null pointer");
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(b2) |
+                         reinterpret_cast<uintptr_t>(out);
+  const int vec = (bits & 15) == 0 && (na & 3) == 0 && (nb & 3) == 0;
+  hipLaunchKernelGGL(concat2_sum_kernel, dim3(grid_for(vec ? (na + nb) / 4 : na + nb)), dim3(256), 0, s, a, na, b, b2, nb, out, vec);
+  TB_LAUNCH_CHECK("concat2_sum_kernel");
   return TB_OK;
 }
 

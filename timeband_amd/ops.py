@@ -911,12 +911,18 @@ def grad_merge(g, g2):
     _lib.call("tb_grad_merge", _ptr(g), _ptr(g2), g.numel(), _stream())
 
 
-def concat2(a, b):
-    """torch.cat([a, b], 0) for contiguous tensors of the same trailing shape, as two device copies."""
+def concat2(a, b, b_add=None):
+    """torch.cat([a, b], 0) for contiguous tensors of the same trailing shape, as two device copies; with `b_add` (float32, b's
+    shape) the second part is b + b_add, formed in the one launch that writes the result."""
     _need_cuda(a, b)
     if a.shape[1:] != b.shape[1:] or a.dtype != b.dtype or not (a.is_contiguous() and b.is_contiguous()):
         raise RuntimeError("concat2: contiguous tensors of the same dtype and trailing shape")
     out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+    if b_add is not None:
+        if b_add.shape != b.shape or a.dtype != torch.float32 or b_add.dtype != torch.float32 or not b_add.is_contiguous():
+            raise RuntimeError("concat2: b_add must be a contiguous float32 tensor of b's shape")
+        _lib.call("tb_concat2_sum", _ptr(a), a.numel(), _ptr(b), _ptr(b_add), b.numel(), _ptr(out), _stream())
+        return out
     _lib.call("tb_concat2", _ptr(a), a.numel() * a.element_size(), _ptr(b), b.numel() * b.element_size(), _ptr(out),
               _stream())
     return out

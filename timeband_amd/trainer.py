@@ -296,7 +296,10 @@ class TIMEBANDTrainer:
                     self._mark("dphase", true_x.device)
                 if ov4 and not share:
                     fake_g, fake_y = fake_y, fake_y.detach().requires_grad_()
-                DGx = netD(fake_y)
+                # joint backward: D reads fake_y through a second leaf on the same values, so that its input gradient and the
+                # loss terms' gradient arrive in two buffers (no accumulation kernel); concat2 below sums them on the way
+                fake_d = fake_y.detach().requires_grad_() if (joint and training) else fake_y
+                DGx = netD(fake_d)
                 errG = self.losses.gen_loss(true_y, fake_y, DGx, presum=presum)
             if training:
                 if not (share or ov4 or joint):
@@ -306,7 +309,7 @@ class TIMEBANDTrainer:
                 if joint:
                     # both generator backward passes (trainer.py:179 through fake_y's graph, :193) as one over 2B rows
                     self.optimG.begin_reduce()
-                    g2 = ops.concat2(leaf_a.grad, fake_y.grad)
+                    g2 = ops.concat2(leaf_a.grad, fake_y.grad, fake_d.grad)
                     if ov1:
                         g2.record_stream(s1)
                         s1.wait_stream(main)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timeline of the LAST step in a rocprofv3 kernel_trace.csv: one line per dispatch with its start
 offset, duration, gap to the previous kernel and grid -- to see per-shape GEMM times and idle gaps.
-usage: python tools/trace_timeline.py kernel_trace.csv [nsteps] [--agg]"""
+usage: python tools/trace_timeline.py kernel_trace.csv [nsteps] [--agg] [--step=N]   (N: 0-based step of the process)"""
 import csv
 import re
 import sys
@@ -14,8 +14,12 @@ nsteps = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 6
 idx = [i for i, r in enumerate(rows) if "window_gather" in r["Kernel_Name"]]
 # two gathers per step (critic batch + main batch): steps begin at every second gather
 starts = idx[::2]
-lo = starts[-2] if len(starts) >= 2 else 0
-hi = starts[-1] if len(starts) >= 2 else len(rows)
+which = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--step=")]
+if which:
+    lo, hi = starts[which[0]], starts[which[0] + 1]
+else:
+    lo = starts[-2] if len(starts) >= 2 else 0
+    hi = starts[-1] if len(starts) >= 2 else len(rows)
 seg = rows[lo:hi]
 t0 = int(seg[0]["Start_Timestamp"])
 prev_end = t0
