@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 timeout -k 10 300 python bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline > "$out/bench.log" 2>&1 || { tail -30 "$out/bench.log"; exit 1; }
 tail -1 "$out/bench.log" > "$out/${rnd}_${cfg}_bench.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --config $cfg --steps $steps --warmup 2 --no-cpu-baseline > "$out/stats.log" 2>&1 || { tail -30 "$out/stats.log"; exit 1; }
-tail -1 "$out/stats.log" > "$out/${rnd}_${cfg}_bench_profiled.json"
+grep "^{\"metric\"" "$out/stats.log" | tail -1 > "$out/${rnd}_${cfg}_bench_profiled.json"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${rnd}_${cfg}_kernel_stats.csv"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --config $cfg --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }

@@ -13,7 +13,7 @@ tail -2 "$out/tests.log"
 timeout -k 10 300 python bench.py > "$out/bench.log" 2>&1 || { tail -30 "$out/bench.log"; exit 1; }
 tail -1 "$out/bench.log" > "$out/${rnd}_bench.json"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/stats.log" 2>&1 || { tail -30 "$out/stats.log"; exit 1; }
-tail -1 "$out/stats.log" > "$out/${rnd}_bench_profiled.json"
+grep "^{\"metric\"" "$out/stats.log" | tail -1 > "$out/${rnd}_bench_profiled.json"
 cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${rnd}_kernel_stats.csv"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1 || { tail -30 "$out/pmc_fetch.log"; exit 1; }
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1 || { tail -30 "$out/pmc_write.log"; exit 1; }

@@ -9,6 +9,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["TB_EXT"] = "0"   # the C++ extension is linked against the regular library: go through ctypes here
 import torch  # noqa: E402
 from timeband_amd import _lib  # noqa: E402
 
