@@ -172,7 +172,7 @@ def run_clean(args, cfg, device):
                 post.step(netG(full.gather(i0, B)["encoded"])[:, :Tf])
             else:                  # the cleaner's path (TIMEBANDCleaner.clean_arrays): windows read in place
                 first = full.row0 + To + (full.w0 + i0) * ds.stride
-                post.step(netG.infer_windows(ds.series_dev, first, B, ds.stride)[:, :Tf])
+                post.step_windows(netG, ds.series_dev, first, B, ds.stride)
 
     kids = {"lstm_fwd": _lib.K_LSTM_FWD, "gemm": _lib.K_GEMM, "band": _lib.K_BAND, "gather": _lib.K_GATHER}
 

@@ -228,6 +228,15 @@ int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in
 int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,
                         const double* dmin, const double* dmax, double band_width, double* med, double* sd,
                         double* lower, double* upper, int rows_out, int smear, void* stream);
+/* tb_dimband_update: the generator's last layer (source/utils/lstm_layer.py:50, Linear(hidden, out_dim) + Tanh) and
+ * tb_band_update_part in ONE kernel for the cleaning / prediction pass (source/cleaner.py:88-106): pred[w][f][:] =
+ * act(hid[w][f][:] . W^T + bias) is formed per band row and sorted in registers, never written to memory.  hid (B, Tf, K)
+ * fp32, W (V, K), act 0 none / 1 tanh / 2 sigmoid.  Outputs as tb_band_update_part, bit for bit; the band history is not
+ * updated (the caller keeps the last Tf-1 windows' predictions).  TB_ERR_UNSUPPORTED (nothing launched) unless
+ * forecast_len <= 48 and K is 32 or 64. */
+int tb_dimband_update(const float* hid, int B, int Tf, int K, const float* W, const float* bias, int act, int V,
+                      const float* hist_in, int nhist, const double* dmin, const double* dmax, double band_width, double* med,
+                      double* sd, double* lower, double* upper, int rows_out, int smear, void* stream);
 int tb_adjust_scan(int variant, const double* seed, const double* reals, const double* preds, const int* masks,
                    const double* lower, const double* upper, int n, int V, double missing_gamma,
                    double anomaly_gamma, double* target, void* stream);

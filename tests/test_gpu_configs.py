@@ -284,7 +284,7 @@ def test_cfg4_full_size_properties(dev):
 
 
 # ---------------------------------------------------------------------------------------------
-def test_cfg5_wide_cleaning_vs_oracle(dev):
+def test_cfg5_wide_cleaning_vs_oracle(dev, monkeypatch):
     """BASELINE.json configs[4] (512 variables, detect + impute through the cleaner path) on a 260-row
     series: device-resident series -> window gather -> G forward -> band -> adjust, against the oracle."""
     from timeband_amd import synthetic
@@ -315,6 +315,12 @@ def test_cfg5_wide_cleaning_vs_oracle(dev):
     want_b = np.concatenate([lower, upper], axis=1)
     assert bands.shape == want_b.shape      # same column order as the reference: lower block then upper block
     assert np.abs(bands - want_b).max() < 5e-4 * scale
+    # the run above formed the generator's output inside the band kernel (tb_dimband_update) for every batch of at least
+    # forecast_len - 1 windows; with the output layer and the band as two kernels the results must be the same bits
+    monkeypatch.setenv("TB_FUSE_DIMBAND", "0")
+    out2, bands2 = TIMEBANDCleaner(cfg, ds, holder).clean(full.loader(B))
+    np.testing.assert_array_equal(out2.to_numpy(), got)
+    np.testing.assert_array_equal(bands2.to_numpy(), bands)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -560,3 +560,42 @@ def test_gradient_housekeeping_ops(dev):
     assert torch.equal(x, want) and not y.any()
     ops.zero_(x)
     assert not x.any()
+
+
+@pytest.mark.parametrize("Tf,K,V", [(48, 64, 512), (12, 64, 37), (24, 32, 600), (5, 32, 16), (33, 64, 130)])
+def test_dimband_update_equals_linear_then_band(dev, Tf, K, V):
+    """tb_dimband_update (the generator's output layer inside the band kernel, predictions never written) against
+    linear_act + tb_band_update_part over several batches with the history carried across them: identical bits, for
+    full and partial row ranges, variables that do not fill a wave or a 512-block, and the smallest batch it takes."""
+    from timeband_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(Tf * 1000 + V)
+    W = ((torch.rand(V, K, generator=g) * 2 - 1) / K ** 0.5).to(dev)
+    b = ((torch.rand(V, generator=g) * 2 - 1) / K ** 0.5).to(dev)
+    dmin = (torch.rand(V, generator=g, dtype=torch.float64) * 5 - 5).to(dev)
+    dmax = dmin + (torch.rand(V, generator=g, dtype=torch.float64) * 8 + 1).to(dev)
+    hist = [torch.zeros(Tf - 1, Tf, V, dtype=torch.float32, device=dev) for _ in range(2)]
+    cur = nh = 0
+    width = 1.5
+    eq = lambda x, y: torch.equal(torch.nan_to_num(x, nan=1e30), torch.nan_to_num(y, nan=1e30))
+    for B in (Tf + 70, Tf - 1, 2 * Tf + 3):
+        hid = (torch.rand(B, Tf, K, generator=g) * 2 - 1).to(dev)
+        pred = ops.linear_act(hid.view(B * Tf, K), W, b, ops.ACT_TANH).view(B, Tf, V)
+        want = ops.band_update(pred, hist[cur], nh, hist[cur ^ 1], width, dmin, dmax)
+        got = ops.dimband_update(hid, W, b, ops.ACT_TANH, hist[cur], nh, width, dmin, dmax)
+        for x, y in zip(got, want):
+            assert eq(x, y)
+        # a rank's own rows, no smear (the data-parallel form of the entry point)
+        want_p = ops.band_update(pred, hist[cur], nh, None, width, dmin, dmax, rows_out=B, smear=False)
+        got_p = ops.dimband_update(hid, W, b, ops.ACT_TANH, hist[cur], nh, width, dmin, dmax, rows_out=B, smear=False)
+        for x, y in zip(got_p, want_p):
+            assert eq(x, y)
+        # without denormalisation
+        want_n = ops.band_update(pred, hist[cur], nh, None, width, rows_out=B + Tf - 1, smear=True)
+        got_n = ops.dimband_update(hid, W, b, ops.ACT_TANH, hist[cur], nh, width)
+        for x, y in zip(got_n, want_n):
+            assert eq(x, y)
+        cur ^= 1
+        nh = min(Tf - 1, nh + B)
+    ops.check_errors(dev)
+    with pytest.raises(RuntimeError):
+        ops.dimband_update(torch.zeros(4, 49, K, device=dev), W, b, ops.ACT_TANH, None, 0, width)   # forecast_len > 48

@@ -73,6 +73,7 @@ SIGNATURES = {
     "tb_denormalize": (I, [P, L, I, P, P, P, P]),
     "tb_band_update": (I, [P, I, I, I, P, I, P, P, P, D, P, P, P, P, P]),
     "tb_band_update_part": (I, [P, I, I, I, P, I, P, P, P, D, P, P, P, P, I, I, P]),
+    "tb_dimband_update": (I, [P, I, I, I, P, P, I, I, P, I, P, P, D, P, P, P, P, I, I, P]),
     "tb_metric_sums": (I, [P, P, P, L, P, P]),
     "tb_metric_finish": (I, [P, I, P, P, P]),
     "tb_adjust_scan": (I, [I, P, P, P, P, P, P, I, I, D, D, P, P]),

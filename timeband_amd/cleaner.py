@@ -29,12 +29,12 @@ class TIMEBANDCleaner:
         in_place = hasattr(dataset, "positions") and os.environ.get("TB_CLEAN_INPLACE", "1") != "0"
         with torch.no_grad():
             for data in (dataset.positions() if in_place else dataset):
+                part = data.get("part") if isinstance(data, dict) else None
                 if "windows" in data:
                     first, count, stride = data["windows"]
-                    fake_y = netG.infer_windows(self.dataset.series_dev, first, count, stride)[:, : self.forecast_len]
+                    post.step_windows(netG, self.dataset.series_dev, first, count, stride, part)
                 else:
-                    fake_y = netG(data["encoded"].to(dev))[:, : self.forecast_len]
-                post.step(fake_y, data.get("part") if isinstance(data, dict) else None)
+                    post.step(netG(data["encoded"].to(dev))[:, : self.forecast_len], part)
         from . import ops
         ops.check_errors(dev)
         n = self.dataset.observed_len + post.idx + self.forecast_len - 1      # rows written so far

@@ -308,6 +308,45 @@ __device__ __forceinline__ void network_sort(float (&a)[NS]) {
   }
 }
 
+// median / population std of the n valid values among a[0..NS) (the others are +inf), and the band where it is final
+template <int NS>
+__device__ __forceinline__ void band_item_tail(float (&a)[NS], int n, long item, int r, double* __restrict__ med,
+                                               double* __restrict__ sd, int direct_rows, double width,
+                                               double* __restrict__ lower, double* __restrict__ upper) {
+  double m_out, s_out;
+  if (n == 0) {
+    m_out = __builtin_nan("");
+    s_out = __builtin_nan("");
+  } else {
+    network_sort<NS>(a);
+    const int lo = (n - 1) >> 1, hi = n >> 1;
+    float mlo = 0.f, mhi = 0.f;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i == lo) mlo = a[i];
+      if (i == hi) mhi = a[i];
+      s += i < n ? (double)a[i] : 0.0;
+    }
+    const double mean = s / (double)n;
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const double d = (double)a[i] - mean;
+      q += i < n ? d * d : 0.0;
+    }
+    m_out = lo == hi ? (double)mlo : ((double)mlo + (double)mhi) / 2.0;   // np.median: mean of the two middle values
+    s_out = sqrt(q / (double)n);
+  }
+  med[item] = m_out;
+  sd[item] = s_out;
+  if (r < direct_rows) {
+    const double w = width * s_out;
+    lower[item] = m_out - w;
+    upper[item] = m_out + w;
+  }
+}
+
 // Rows below `direct_rows` (those the std smear does not touch) get their band written here; band_finish_kernel does the rest.
 template <int NS>
 __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict__ pden, int B, int Tf, int V, int nrows,
@@ -340,37 +379,160 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
     n += ok ? 1 : 0;
     a[f] = ok ? x : __builtin_inff();
   }
-  double m_out, s_out;
-  if (n == 0) {
-    m_out = __builtin_nan("");
-    s_out = __builtin_nan("");
-  } else {
-    network_sort<NS>(a);
-    const int lo = (n - 1) >> 1, hi = n >> 1;
-    float mlo = 0.f, mhi = 0.f;
-    double s = 0.0;
+  band_item_tail<NS>(a, n, item, r, med, sd, direct_rows, width, lower, upper);
+}
+
+// ---- K6b last linear layer + band in one kernel (cleaning pass, forecast_len <= 48, hidden <= 64) ----------------------
+// The generator ends in out[w][f][:] = act(hid[w][f][:] . W^T + b) (lstm_layer.py:50: Linear(hidden, out_dim) + Tanh over the
+// (windows x forecast_len) rows), and the band of series row r is taken over out[r - f][f][:], f = 0 .. Tf-1.  Written to
+// HBM and read back, `out` is the largest tensor of the pass (805 MB per 8192 windows at 512 variables) and nothing else
+// reads it but the band history (the last Tf-1 windows, kept by the caller).  Here a workgroup takes a row r, gathers its
+// Tf hidden rows hid[r - f][f][0..KD) -- each hidden row belongs to exactly one r --, forms the Tf x V forecasts on the
+// matrix cores and sorts them in registers.  Wave w of the 8 owns variables [64 w, 64 w + 64) (+ 512 blockIdx.y): its
+// W rows stay in registers as split bf16 for the whole launch.  The products replicate the GEMM kernel's arithmetic for
+// this shape operation by operation (first operand W, k-tiles of 32 ascending, lo.hi, hi.lo, hi.hi, then bias, then tanhf),
+// so the forecasts -- and with them the band -- are the same bits as on the two-kernel path.
+template <int NS, int KD>
+__global__ __launch_bounds__(512, 1) void dimband_kernel(const float* __restrict__ hid, int B, int Tf, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, int act, int V, int nrows,
+                                                         const float* __restrict__ hist, int nhist,
+                                                         const double* __restrict__ dmin, const double* __restrict__ dmax,
+                                                         double* __restrict__ med, double* __restrict__ sd, int direct_rows,
+                                                         double width, double* __restrict__ lower, double* __restrict__ upper) {
+  constexpr int NFT = (NS + 15) / 16;          // 16-wide forecast tiles
+  constexpr int FR = NFT * 16;                 // rows of the hidden tile
+  constexpr int NKS = KD / 32;                 // 32-deep k-steps
+  constexpr int LDA = KD + 8;                  // hidden tile row stride (bf16 elements)
+  constexpr int PLD = 64 + 4;                  // forecast patch row stride (floats)
+  constexpr int NCHUNK = FR * KD / 4, NCH = (NCHUNK + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_db[];
+  // [2 buffers][hi | lo][FR][LDA], then per wave a [FR][PLD] patch of forecasts
+  float* patch_all = reinterpret_cast<float*>(lds_db + 2 * 2 * FR * LDA);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, q = lane >> 4;
+  const int vbase = blockIdx.y * 512 + wave * 64;
+  float* patch = patch_all + wave * FR * PLD;
+  const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)hid, 0, (int)((long)B * Tf * KD * 4), 0x00020000);
+  // W rows of this wave's 64 variables as the MFMA's first operand: lane (col, q) holds W[v = vt*16 + col][k = s*32 + q*8 ..]
+  bf16x8 wh[4][NKS], wl[4][NKS];
+  f32x4 bv[4];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (i == lo) mlo = a[i];
-      if (i == hi) mhi = a[i];
-      s += i < n ? (double)a[i] : 0.0;
-    }
-    const double mean = s / (double)n;
-    double q = 0.0;
+  for (int vt = 0; vt < 4; ++vt) {
+    const int v = vbase + vt * 16 + col;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      const double d = (double)a[i] - mean;
-      q += i < n ? d * d : 0.0;
+    for (int s = 0; s < NKS; ++s) {
+      f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+      if (v < V) {
+        w0 = *reinterpret_cast<const f32x4*>(W + (long)v * KD + s * 32 + q * 8);
+        w1 = *reinterpret_cast<const f32x4*>(W + (long)v * KD + s * 32 + q * 8 + 4);
+      }
+      tb_split8(w0, w1, wh[vt][s], wl[vt][s]);
     }
-    m_out = lo == hi ? (double)mlo : ((double)mlo + (double)mhi) / 2.0;   // np.median: mean of the two middle values
-    s_out = sqrt(q / (double)n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int vb = vbase + vt * 16 + q * 4 + i;
+      bv[vt][i] = (bias && vb < V) ? bias[vb] : 0.f;
+    }
   }
-  med[item] = m_out;
-  sd[item] = s_out;
-  if (r < direct_rows) {
-    const double w = width * s_out;
-    lower[item] = m_out - w;
-    upper[item] = m_out + w;
+  const int v = vbase + lane;                  // the variable this lane sorts
+  const bool vok = v < V;
+  const double mn = (dmin && vok) ? dmin[v] : 0.0, mx = (dmin && vok) ? dmax[v] : 0.0;
+
+  auto load_rows = [&](int r, f32x4 (&ra)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = tid + 512 * c, f = e / (KD / 4), k4 = e % (KD / 4);
+      const int w = r - f;
+      const bool ok = e < NCHUNK && f < Tf && w >= 0 && w < B && r < nrows;
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rH, ok ? (int)((((long)w * Tf + f) * KD + k4 * 4) * 4) : 0x7FFFFFF0, 0, 0));
+    }
+  };
+  auto store_rows = [&](int b, const f32x4 (&ra)[NCH]) {
+    unsigned short* hi = lds_db + b * 2 * FR * LDA;
+    unsigned short* lo = hi + FR * LDA;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int e = tid + 512 * c, f = e / (KD / 4), k4 = e % (KD / 4);
+      if (e < NCHUNK) {
+        u32x2 sh, sl;
+        tb_split4(ra[c], sh, sl);
+        *reinterpret_cast<u32x2*>(hi + f * LDA + k4 * 4) = sh;
+        *reinterpret_cast<u32x2*>(lo + f * LDA + k4 * 4) = sl;
+      }
+    }
+  };
+  f32x4 ra[NCH];
+  int r = blockIdx.x;
+  load_rows(r, ra);
+  store_rows(0, ra);
+  __syncthreads();
+  int b = 0;
+  for (; r < nrows; r += gridDim.x, b ^= 1) {
+    load_rows(r + gridDim.x, ra);              // the next row's hidden rows, in flight under this row's work
+    const unsigned short* Ah = lds_db + b * 2 * FR * LDA;
+    const unsigned short* Al = Ah + FR * LDA;
+    f32x4 acc[4][NFT];
+#pragma unroll
+    for (int vt = 0; vt < 4; ++vt)
+#pragma unroll
+      for (int ft = 0; ft < NFT; ++ft) acc[vt][ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+      for (int ft = 0; ft < NFT; ++ft) {
+        const int ao = (ft * 16 + col) * LDA + s * 32 + q * 8;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Ah + ao));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Al + ao));
+#pragma unroll
+        for (int vt = 0; vt < 4; ++vt) acc[vt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[vt][s], ah, acc[vt][ft], 0, 0, 0);
+#pragma unroll
+        for (int vt = 0; vt < 4; ++vt) acc[vt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[vt][s], al, acc[vt][ft], 0, 0, 0);
+#pragma unroll
+        for (int vt = 0; vt < 4; ++vt) acc[vt][ft] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[vt][s], ah, acc[vt][ft], 0, 0, 0);
+      }
+    }
+    // bias, activation; lane (col, q) holds variables vt*16 + q*4 .. +3 of forecast step ft*16 + col: into the wave's patch
+#pragma unroll
+    for (int vt = 0; vt < 4; ++vt)
+#pragma unroll
+      for (int ft = 0; ft < NFT; ++ft) {
+        f32x4 o = acc[vt][ft];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          o[i] += bv[vt][i];
+          if (act == 1) o[i] = tanhf(o[i]);
+          else if (act == 2) o[i] = tb_sigmoid(o[i]);
+        }
+        *reinterpret_cast<f32x4*>(patch + (ft * 16 + col) * PLD + vt * 16 + q * 4) = o;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // this lane's variable: its forecasts for row r at every horizon (window r - f; the history / NaN where that
+    // window is not in this batch), denormalised like the two-kernel path
+    float a[NS];
+    int n = 0;
+    const bool edge = r < Tf - 1 || r >= B;    // some window of this row lies outside the batch (workgroup-uniform)
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      float x = patch[f * PLD + lane];
+      if (edge) {
+        const int w = r - f;
+        const bool inb = f < Tf && w >= 0 && w < B;
+        const bool inh = f < Tf && w < 0 && -w <= nhist && hist != nullptr && vok;
+        const float hx = inh ? hist[((long)(Tf - 1 + w) * Tf + f) * V + v] : 0.f;
+        x = inb ? x : (inh ? hx : __builtin_nanf(""));
+      } else if (f >= Tf) {
+        x = __builtin_nanf("");
+      }
+      if (dmin) x = denorm1(x, mn, mx);   // NaN stays NaN
+      const bool ok = !isnan(x);
+      n += ok ? 1 : 0;
+      a[f] = ok ? x : __builtin_inff();
+    }
+    __builtin_amdgcn_wave_barrier();           // the patch is free for the next row
+    if (vok) band_item_tail<NS>(a, n, (long)r * V + v, r, med, sd, direct_rows, width, lower, upper);
+    store_rows(b ^ 1, ra);
+    __syncthreads();
   }
 }
 
@@ -645,6 +807,43 @@ int tb_denormalize(const float* x, long n, int V, const double* dmin, const doub
   return TB_OK;
 }
 
+}  // extern "C"
+namespace {
+// the std smear over the last Tf rows and the band of the rows the sort kernel left (those the smear changes)
+int band_smear_finish(double* sd, const double* med, double* lower, double* upper, int R, int Tf, int V, int rows_out, int smear,
+                      int direct_rows, double band_width, hipStream_t s) {
+  const long nitems = (long)rows_out * V;
+  if (smear) {
+    hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
+    TB_LAUNCH_CHECK("band_smear_kernel");
+  }
+  if (direct_rows < rows_out) {
+    const long first = (long)direct_rows * V;
+    hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems - first)), dim3(256), 0, s, med, sd, first, nitems, band_width,
+                       lower, upper);
+    TB_LAUNCH_CHECK("band_finish_kernel");
+  }
+  return TB_OK;
+}
+
+template <int NS, int KD>
+int launch_dimband(dim3 g, size_t lds, hipStream_t s, const float* hid, int B, int Tf, const float* W, const float* bias, int act,
+                   int V, int rows_out, const float* hist_in, int nhist, const double* dmin, const double* dmax, double* med,
+                   double* sd, int direct_rows, double width, double* lower, double* upper) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    TB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dimband_kernel<NS, KD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dimband_kernel<NS, KD>), g, dim3(512), lds, s, hid, B, Tf, W, bias, act, V, rows_out, hist_in, nhist, dmin,
+                     dmax, med, sd, direct_rows, width, lower, upper);
+  TB_LAUNCH_CHECK("dimband_kernel");
+  return TB_OK;
+}
+}  // namespace
+extern "C" {
+
 // pden: (B,Tf,V) predictions of this batch.  hist_in/hist_out: (Tf-1,Tf,V) predictions of the last Tf-1
 // windows before / after this batch (distinct buffers), nhist = valid windows in hist_in.
 // med/sd/lower/upper: float64 outputs of `rows_out` rows (sd is returned AFTER the smear).
@@ -686,16 +885,8 @@ int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hi
                        lds, s, pden, B, Tf, V, rows_out, hist_in, nhist, dmin, dmax, med, sd);
     TB_LAUNCH_CHECK("band_kernel");
   }
-  if (smear) {
-    hipLaunchKernelGGL(band_smear_kernel, dim3((V + 63) / 64), dim3(64), 0, s, sd, R, Tf, V);
-    TB_LAUNCH_CHECK("band_smear_kernel");
-  }
-  if (direct_rows < rows_out) {
-    const long first = (long)direct_rows * V;
-    hipLaunchKernelGGL(band_finish_kernel, dim3(grid_for(nitems - first)), dim3(256), 0, s, med, sd, first, nitems, band_width,
-                       lower, upper);
-    TB_LAUNCH_CHECK("band_finish_kernel");
-  }
+  int rc = band_smear_finish(sd, med, lower, upper, R, Tf, V, rows_out, smear, direct_rows, band_width, s);
+  if (rc) return rc;
   if (hist_out) {
     hipLaunchKernelGGL(hist_update_kernel, dim3(grid_for((long)(Tf - 1) * Tf * V)), dim3(256), 0, s, pden, B, Tf, V,
                        hist_in, hist_out);
@@ -703,6 +894,52 @@ int tb_band_update_part(const float* pden, int B, int Tf, int V, const float* hi
   }
   tb_prof_end(TB_K_BAND, s);
   return TB_OK;
+}
+
+// tb_dimband_update: tb_band_update_part for predictions that are still to be formed -- pred[w][f][:] = act(hid[w][f][:] . W^T
+// + bias), hid (B, Tf, K) the generator's last hidden buffer, W (V, K) -- without writing them to memory (dimband_kernel).
+// Same outputs, bit for bit, as the linear layer followed by tb_band_update_part on its result; the band history is not
+// touched (the caller keeps the last Tf-1 windows' predictions for the next batch).  Supported: forecast_len <= 48 (the eight
+// waves' forecast patches have to fit the LDS),
+// K = 32 or 64, act 0 / 1 (tanh) / 2 (sigmoid); anything else returns TB_ERR_UNSUPPORTED before any launch.
+int tb_dimband_update(const float* hid, int B, int Tf, int K, const float* W, const float* bias, int act, int V,
+                      const float* hist_in, int nhist, const double* dmin, const double* dmax, double band_width, double* med,
+                      double* sd, double* lower, double* upper, int rows_out, int smear, void* stream) {
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B <= 0) return TB_OK;
+  if (Tf < 2) return tb_set_error(TB_ERR_ARG, "dimband_update: forecast_len must be >= 2 (the reference divides by Tf-1)");
+  if (Tf > 48 || (K != 32 && K != 64) || act < 0 || act > 2)
+    return tb_set_error(TB_ERR_UNSUPPORTED, "dimband_update: forecast_len %d / hidden %d / act %d not supported", Tf, K, act);
+  if (!hid || !W || !med || !sd || !lower || !upper || V < 1) return tb_set_error(TB_ERR_ARG, "dimband_update: bad pointer");
+  if ((reinterpret_cast<uintptr_t>(hid) | reinterpret_cast<uintptr_t>(W)) & 15)
+    return tb_set_error(TB_ERR_ARG, "dimband_update: hid and W must be 16-byte aligned");
+  if (nhist < 0 || nhist > Tf - 1 || (nhist > 0 && !hist_in)) return tb_set_error(TB_ERR_ARG, "dimband_update: nhist out of range");
+  if ((dmin == nullptr) != (dmax == nullptr)) return tb_set_error(TB_ERR_ARG, "dimband_update: dmin and dmax go together");
+  if ((long)B * Tf * K * 4 > 0x7FFFFFF0l) return tb_set_error(TB_ERR_UNSUPPORTED, "dimband_update: hidden buffer over 2 GiB");
+  const int R = B + Tf - 1;
+  if (rows_out < 1 || rows_out > R) return tb_set_error(TB_ERR_ARG, "dimband_update: rows_out %d outside [1, %d]", rows_out, R);
+  if (smear && rows_out != R) return tb_set_error(TB_ERR_ARG, "dimband_update: the std smear needs every row (rows_out == B+Tf-1)");
+  const int direct_rows = smear ? (R - Tf > 0 ? R - Tf : 0) : rows_out;
+  const int ny = (V + 511) / 512;
+  int gx = tb_num_cus() / ny;
+  if (gx < 1) gx = 1;
+  if (gx > rows_out) gx = rows_out;
+  const dim3 g((unsigned)gx, (unsigned)ny);
+  const int NS = Tf <= 16 ? 16 : (Tf <= 32 ? 32 : 48);
+  const size_t lds = (size_t)2 * 2 * NS * (K + 8) * sizeof(unsigned short) + (size_t)8 * NS * (64 + 4) * sizeof(float);
+  tb_prof_begin(TB_K_BAND, s);
+  int rc = TB_OK;
+#define TB_DIMBAND_CASE(ns, kd)                                                                                                   \
+  if (NS == ns && K == kd)                                                                                                        \
+    rc = launch_dimband<ns, kd>(g, lds, s, hid, B, Tf, W, bias, act, V, rows_out, hist_in, nhist, dmin, dmax, med, sd, direct_rows, \
+                                band_width, lower, upper);
+  TB_DIMBAND_CASE(16, 32) TB_DIMBAND_CASE(32, 32) TB_DIMBAND_CASE(48, 32)
+  TB_DIMBAND_CASE(16, 64) TB_DIMBAND_CASE(32, 64) TB_DIMBAND_CASE(48, 64)
+#undef TB_DIMBAND_CASE
+  if (rc) return rc;
+  rc = band_smear_finish(sd, med, lower, upper, R, Tf, V, rows_out, smear, direct_rows, band_width, s);
+  tb_prof_end(TB_K_BAND, s);
+  return rc;
 }
 
 int tb_band_update(const float* pden, int B, int Tf, int V, const float* hist_in, int nhist, float* hist_out,

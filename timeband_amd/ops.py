@@ -843,6 +843,35 @@ def band_update(pden, hist_in, nhist, hist_out, band_width, dmin=None, dmax=None
     return med, lower, upper
 
 
+def dimband_supported(Tf, K):
+    """Shapes tb_dimband_update takes (the others go through linear_act + band_update)."""
+    return 2 <= Tf <= 48 and K in (32, 64)
+
+
+def dimband_update(hid, weight, bias, act, hist_in, nhist, band_width, dmin=None, dmax=None, rows_out=None, smear=True):
+    """band_update(act(hid . weight^T + bias), ...) in one kernel, the predictions never written to memory: hid (B, Tf, K) the
+    generator's last hidden buffer, weight (V, K).  The band history is NOT updated here (see BandAdjust.step_hidden).
+    Same results bit for bit as the two-kernel path."""
+    _need_cuda(hid, weight, hist_in)
+    if dmin is not None:
+        dmin, dmax = _c(dmin, torch.float64), _c(dmax, torch.float64)
+    hid, weight = _f32c(hid), _f32c(weight)
+    bias = None if bias is None else _f32c(bias)
+    B, Tf, K = hid.shape
+    V = weight.shape[0]
+    if weight.shape[1] != K or not dimband_supported(Tf, K):
+        raise RuntimeError(f"dimband_update: unsupported shape hid {tuple(hid.shape)} weight {tuple(weight.shape)}")
+    if hist_in is not None and (hist_in.shape != (Tf - 1, Tf, V) or not hist_in.is_contiguous() or hist_in.dtype != torch.float32):
+        raise RuntimeError("dimband_update: the history must be contiguous float32 (Tf-1,Tf,V)")
+    R = B + Tf - 1 if rows_out is None else int(rows_out)
+    mk = lambda: torch.empty(R, V, dtype=torch.float64, device=hid.device)
+    med, sd, lower, upper = mk(), mk(), mk(), mk()
+    _lib.call("tb_dimband_update", _ptr(hid), B, Tf, K, _ptr(weight), _ptr(bias), int(act), V, _ptr(hist_in), int(nhist),
+              _ptr(dmin), _ptr(dmax), float(band_width), _ptr(med), _ptr(sd), _ptr(lower), _ptr(upper), R, 1 if smear else 0,
+              _stream())
+    return med, lower, upper
+
+
 VARIANTS = {"trainer": 0, "cleaner": 1, "predictor": 2}
 
 

@@ -15,6 +15,8 @@ rank back to rank 0 as the next batch's seed row (the reference seeds each batch
 row of the previous one, trainer.py:209).  Slices shorter than forecast_len-1 windows fall back to an
 all-gather of the predictions and the single-rank arithmetic on every rank.
 """
+import os
+
 import torch
 
 from . import dp, ops
@@ -28,6 +30,7 @@ class BandAdjust:
         self.ds, self.variant = dataset, variant
         self.w, self.a, self.b = band_width, missing_gamma, anomaly_gamma
         self.keep = keep_outputs
+        self.fuse_last_layer = os.environ.get("TB_FUSE_DIMBAND", "1") != "0"   # step_windows: output layer inside the band kernel
         if out_dtype is None:
             dev = dataset.series_dev.device
             big = dev.type == "cuda" and 3 * dataset.data_length * dataset.decode_dim * 8 > \
@@ -76,6 +79,32 @@ class BandAdjust:
             self._sync_state()
         return self._step_all(fake_y)
 
+    def step_windows(self, netG, series, first, count, stride=1, part=None):
+        """One cleaning / prediction batch from window POSITIONS (the windows whose forecasts start at series rows first,
+        first + stride, ...): generator forward over the windows in place, then step().  Where the shapes allow it
+        (ops.dimband_supported, single rank, whole forecasts used) the generator's output layer runs INSIDE the band
+        kernel and the (count, Tf, V) predictions are never written: same results bit for bit."""
+        Tf = self.ds.forecast_len
+        fuse = (self.fuse_last_layer and part is None and netG.outseq_len == Tf and count >= Tf - 1 and series.is_cuda
+                and ops.dimband_supported(Tf, netG.hidden_dim))
+        if not fuse:
+            return self.step(netG.infer_windows(series, first, count, stride)[:, :Tf], part)
+        return self.step_hidden(netG, netG.infer_windows(series, first, count, stride, hidden=True))
+
+    def step_hidden(self, netG, hid):
+        """_step_all for predictions that exist only as the generator's last hidden buffer `hid` (B, Tf, hidden)."""
+        d = self.ds
+        self.full_rows = True
+        B, Tf, K = hid.shape
+        dim = netG.dim_layer[0]
+        preds, lower, upper = ops.dimband_update(hid, dim.weight.detach(), dim.bias.detach(), ops.ACT_TANH, self.hist[self.cur],
+                                                 self.nhist, self.w, d.dmin_dev, d.dmax_dev)
+        # the next batch's history: the last Tf-1 windows' predictions, from the same layer on just those windows
+        self.hist[self.cur ^ 1] = netG.last_layer(hid[B - (Tf - 1):]).contiguous()
+        self.cur ^= 1
+        self.nhist = Tf - 1
+        return self._adjust_all(B, Tf, preds, lower, upper)
+
     def _sync_state(self):
         """Before a step that every rank runs in full: the band history and the adjust seed row live on rank 0
         after sharded steps (the ring shift and the carry end there) -- hand them to everybody."""
@@ -101,6 +130,10 @@ class BandAdjust:
                                               self.w, d.dmin_dev, d.dmax_dev)
         self.cur ^= 1
         self.nhist = min(Tf - 1, self.nhist + B)
+        return self._adjust_all(B, Tf, preds, lower, upper)
+
+    def _adjust_all(self, B, Tf, preds, lower, upper):
+        d = self.ds
         n = B + Tf - 1
         if self.idx + n > d.forecast_dev.shape[0]:
             raise RuntimeError("post-processing ran past the end of the series")

@@ -58,12 +58,14 @@ class LSTMGenerator(nn.Module):
         return out.view(B, self.outseq_len, self.out_dim)
 
 
-    def infer_windows(self, series, first, nwin, stride=1):
+    def infer_windows(self, series, first, nwin, stride=1, hidden=False):
         """self(windows) without a graph for the `nwin` windows whose encoder rows are series rows
         [first + w * stride - inseq_len, first + w * stride) -- the cleaning / prediction pass (cleaner.py:67-68 over the
         windows of dataset.py:207-212).  The windows overlap, so the first layer's input projection is computed once per
         SERIES row and the recurrent kernel reads it in place (ops.lstm_fwd_windows): the encoder windows are never
-        gathered and the projection costs inseq_len / stride times fewer flops.  Bit-identical to self(gathered windows)."""
+        gathered and the projection costs inseq_len / stride times fewer flops.  Bit-identical to self(gathered windows).
+        hidden=True: stop in front of the last layer and return its input, the (nwin, outseq_len, hidden_dim) buffer -- the
+        caller forms the output inside the band kernel (BandAdjust.step_hidden)."""
         To = self.inseq_len
         l0 = self.lstm0
         r0 = first - To
@@ -84,8 +86,18 @@ class LSTMGenerator(nn.Module):
                 r = ops.lstm_stack(r, getattr(self, f"lstm{i}"))
             seq, dim = self.seq_layer[0], self.dim_layer[0]
             s = ops.linear_act(r.view(nwin * self.hidden_dim, To), seq.weight, seq.bias, ops.ACT_NONE)
+            if hidden:
+                return s.view(nwin, self.outseq_len, self.hidden_dim)
             out = ops.linear_act(s.view(nwin * self.outseq_len, self.hidden_dim), dim.weight, dim.bias, ops.ACT_TANH)
         return out.view(nwin, self.outseq_len, self.out_dim)
+
+    def last_layer(self, hid):
+        """The output layer on a (n, outseq_len, hidden_dim) buffer of infer_windows(hidden=True) (no graph)."""
+        dim = self.dim_layer[0]
+        n = hid.shape[0]
+        with torch.no_grad():
+            out = ops.linear_act(hid.reshape(n * self.outseq_len, self.hidden_dim), dim.weight, dim.bias, ops.ACT_TANH)
+        return out.view(n, self.outseq_len, self.out_dim)
 
     def twin_joint(self, input):
         """twin() with ONE autograd graph over the 2B rows: returns (out2, fake_a, fake_b) -- out2 (2B, Tf, V) carries
