@@ -55,6 +55,10 @@ static inline size_t tb_align_up(size_t x, size_t a) { return (x + a - 1) / a * 
 
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ float tb_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// tanh of a layer output (Linear + Tanh): 1 - 2 / (1 + e^(2x)) on the hardware exp and reciprocal -- absolute error ~2e-7 on
+// values in (-1, 1), six instructions where tanhf is a branchy ~30.  ONE definition for every kernel that applies the
+// activation (GEMM epilogues, the split-K finish, the fused output-layer + band kernel), so they agree bit for bit.
+__device__ __forceinline__ float tb_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 // Agent-scope (write-through / L1-bypassing) accesses used for the in-launch hand-offs
 // between the workgroups of one cluster (guide: cdna_hip_programming.md Guideline 16).

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 v[r] += bv[r];
-                if (a.act == 1) v[r] = tanhf(v[r]);
+                if (a.act == 1) v[r] = tb_tanh(v[r]);
                 else if (a.act == 2) v[r] = tb_sigmoid(v[r]);
               }
             }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += bv[r];
-            if (a.act == 1) v[r] = tanhf(v[r]);
+            if (a.act == 1) v[r] = tb_tanh(v[r]);
             else if (a.act == 2) v[r] = tb_sigmoid(v[r]);
           }
         }
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void gemm_big_kernel(GemmArgs a) {
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             v[r4] += bv[r4];
-            if (a.act == 1) v[r4] = tanhf(v[r4]);
+            if (a.act == 1) v[r4] = tb_tanh(v[r4]);
             else if (a.act == 2) v[r4] = tb_sigmoid(v[r4]);
           }
         }
@@ -642,7 +642,7 @@ __global__ void splitk_final_kernel(const float* __restrict__ slab, int splits, 
     for (int z = 0; z < splits; z += zstep) s += slab[(size_t)z * total + i];
     const int m = (int)(i / N), n = (int)(i % N);
     if (bias || bias2) s += (bias ? bias[n] : 0.f) + (bias2 ? bias2[n] : 0.f);
-    if (act == 1) s = tanhf(s);
+    if (act == 1) s = tb_tanh(s);
     else if (act == 2) s = tb_sigmoid(s);
     if (accumulate) s += C[(long)m * ldc + n];
     C[(long)m * ldc + n] = s;

@@ -7,6 +7,7 @@
 // multiply-add that numpy performs as two rounded operations is kept as two (no fma contraction).
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -314,11 +315,28 @@ __device__ __forceinline__ void band_item_tail(float (&a)[NS], int n, long item,
                                                double* __restrict__ sd, int direct_rows, double width,
                                                double* __restrict__ lower, double* __restrict__ upper) {
   double m_out, s_out;
-  if (n == 0) {
+  // Every slot of every lane valid (interior rows of a forecast_len that fills the slots: the bulk of a cleaning sweep):
+  // the median's positions are constants and no sum needs a mask -- the same operations on the same values in the same
+  // order as the general form below, without its ~100 compares, ~400 selects and the mask registers they pin.
+  network_sort<NS>(a);   // (a lane without a valid value sorts its +inf: harmless, and ONE copy of the network in the code)
+  if (__builtin_amdgcn_ballot_w64(n != NS) == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s += (double)a[i];
+    const double mean = s / (double)NS;
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const double d = (double)a[i] - mean;
+      q += d * d;
+    }
+    constexpr int lo = (NS - 1) >> 1, hi = NS >> 1;
+    m_out = lo == hi ? (double)a[lo] : ((double)a[lo] + (double)a[hi]) / 2.0;
+    s_out = sqrt(q / (double)NS);
+  } else if (n == 0) {
     m_out = __builtin_nan("");
     s_out = __builtin_nan("");
   } else {
-    network_sort<NS>(a);
     const int lo = (n - 1) >> 1, hi = n >> 1;
     float mlo = 0.f, mhi = 0.f;
     double s = 0.0;
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(256) void band_sort_kernel(const float* __restrict_
 // Tf hidden rows hid[r - f][f][0..KD) -- each hidden row belongs to exactly one r --, forms the Tf x V forecasts on the
 // matrix cores and sorts them in registers.  Wave w of the 8 owns variables [64 w, 64 w + 64) (+ 512 blockIdx.y): its
 // W rows stay in registers as split bf16 for the whole launch.  The products replicate the GEMM kernel's arithmetic for
-// this shape operation by operation (first operand W, k-tiles of 32 ascending, lo.hi, hi.lo, hi.hi, then bias, then tanhf),
+// this shape operation by operation (first operand W, k-tiles of 32 ascending, lo.hi, hi.lo, hi.hi, then bias, then tb_tanh),
 // so the forecasts -- and with them the band -- are the same bits as on the two-kernel path.
 template <int NS, int KD>
 __global__ __launch_bounds__(512, 1) void dimband_kernel(const float* __restrict__ hid, int B, int Tf, const float* __restrict__ W,
@@ -492,38 +510,46 @@ __global__ __launch_bounds__(512, 1) void dimband_kernel(const float* __restrict
       }
     }
     // bias, activation; lane (col, q) holds variables vt*16 + q*4 .. +3 of forecast step ft*16 + col: into the wave's patch
+    // (ONE branch on the activation around the whole block: inside the loops it is four scalar branches per value)
+    auto emit = [&](auto kind) {
 #pragma unroll
-    for (int vt = 0; vt < 4; ++vt)
+      for (int vt = 0; vt < 4; ++vt)
 #pragma unroll
-      for (int ft = 0; ft < NFT; ++ft) {
-        f32x4 o = acc[vt][ft];
+        for (int ft = 0; ft < NFT; ++ft) {
+          f32x4 o = acc[vt][ft];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o[i] += bv[vt][i];
-          if (act == 1) o[i] = tanhf(o[i]);
-          else if (act == 2) o[i] = tb_sigmoid(o[i]);
+          for (int i = 0; i < 4; ++i) {
+            o[i] += bv[vt][i];
+            if (decltype(kind)::value == 1) o[i] = tb_tanh(o[i]);
+            else if (decltype(kind)::value == 2) o[i] = tb_sigmoid(o[i]);
+          }
+          *reinterpret_cast<f32x4*>(patch + (ft * 16 + col) * PLD + vt * 16 + q * 4) = o;
         }
-        *reinterpret_cast<f32x4*>(patch + (ft * 16 + col) * PLD + vt * 16 + q * 4) = o;
-      }
+    };
+    if (act == 1) emit(std::integral_constant<int, 1>{});
+    else if (act == 2) emit(std::integral_constant<int, 2>{});
+    else emit(std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // this lane's variable: its forecasts for row r at every horizon (window r - f; the history / NaN where that
     // window is not in this batch), denormalised like the two-kernel path
     float a[NS];
-    int n = 0;
-    const bool edge = r < Tf - 1 || r >= B;    // some window of this row lies outside the batch (workgroup-uniform)
 #pragma unroll
-    for (int f = 0; f < NS; ++f) {
-      float x = patch[f * PLD + lane];
-      if (edge) {
+    for (int f = 0; f < NS; ++f) a[f] = patch[f * PLD + lane];      // all reads in flight together
+    if (r < Tf - 1 || r >= B || Tf < NS) {     // some horizon of this row has no window in the batch (workgroup-uniform)
+#pragma unroll
+      for (int f = 0; f < NS; ++f) {
         const int w = r - f;
         const bool inb = f < Tf && w >= 0 && w < B;
         const bool inh = f < Tf && w < 0 && -w <= nhist && hist != nullptr && vok;
         const float hx = inh ? hist[((long)(Tf - 1 + w) * Tf + f) * V + v] : 0.f;
-        x = inb ? x : (inh ? hx : __builtin_nanf(""));
-      } else if (f >= Tf) {
-        x = __builtin_nanf("");
+        a[f] = inb ? a[f] : (inh ? hx : __builtin_nanf(""));
       }
+    }
+    int n = 0;
+#pragma unroll
+    for (int f = 0; f < NS; ++f) {
+      float x = a[f];
       if (dmin) x = denorm1(x, mn, mx);   // NaN stays NaN
       const bool ok = !isnan(x);
       n += ok ? 1 : 0;
