@@ -1482,7 +1482,13 @@ __global__ void wgrad_finish_kernel(WFinishArgs f) {
       const TbGemmDeferred& g = i < n0 ? f.g[0] : f.g[1];
       const long e = i < n0 ? i : i - n0, n = i < n0 ? n0 : n1;
       float s = 0.f;
-      for (int z = 0; z < g.splits; ++z) s += g.slab[(size_t)z * n + e];
+      for (int z0 = 0; z0 < g.splits; z0 += 16) {   // sixteen slabs in flight, added in slab order (one load after the other: a
+        float v[16];                                // 512-slab sum took 65-110 us at cfg1's unaligned input width)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = z0 + u < g.splits ? g.slab[(size_t)(z0 + u) * n + e] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
       float* c = g.C + (e / g.N) * g.ldc + e % g.N;
       *c = g.accumulate ? *c + s : s;
     } else {
