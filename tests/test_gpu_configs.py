@@ -321,6 +321,13 @@ def test_cfg5_wide_cleaning_vs_oracle(dev, monkeypatch):
     out2, bands2 = TIMEBANDCleaner(cfg, ds, holder).clean(full.loader(B))
     np.testing.assert_array_equal(out2.to_numpy(), got)
     np.testing.assert_array_equal(bands2.to_numpy(), bands)
+    # ... and so must the sweep without its pipeline (generator forward of batch i + 1 on a side stream under the band /
+    # adjust of batch i: postprocess.WindowSweep) -- everything on one stream, batch after batch
+    monkeypatch.delenv("TB_FUSE_DIMBAND")
+    monkeypatch.setenv("TB_CLEAN_PIPELINE", "0")
+    out3, bands3 = TIMEBANDCleaner(cfg, ds, holder).clean(full.loader(B))
+    np.testing.assert_array_equal(out3.to_numpy(), got)
+    np.testing.assert_array_equal(bands3.to_numpy(), bands)
 
 
 # ---------------------------------------------------------------------------------------------

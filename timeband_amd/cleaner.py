@@ -27,14 +27,24 @@ class TIMEBANDCleaner:
         # from the device-resident series (no gathered copy, the first projection once per series row); any other
         # iterable of {"encoded": ...} batches (the reference's DataLoader shape) works as before
         in_place = hasattr(dataset, "positions") and os.environ.get("TB_CLEAN_INPLACE", "1") != "0"
+        sweep = None
         with torch.no_grad():
             for data in (dataset.positions() if in_place else dataset):
                 part = data.get("part") if isinstance(data, dict) else None
                 if "windows" in data:
                     first, count, stride = data["windows"]
-                    post.step_windows(netG, self.dataset.series_dev, first, count, stride, part)
+                    if part is None:     # one rank: generator forward of the next batch under this batch's band / adjust
+                        if sweep is None or sweep.stride != stride:
+                            if sweep is not None:
+                                sweep.flush()
+                            sweep = post.sweep(netG, self.dataset.series_dev, stride)
+                        sweep.push(first, count)
+                    else:
+                        post.step_windows(netG, self.dataset.series_dev, first, count, stride, part)
                 else:
                     post.step(netG(data["encoded"].to(dev))[:, : self.forecast_len], part)
+            if sweep is not None:
+                sweep.flush()
         from . import ops
         ops.check_errors(dev)
         n = self.dataset.observed_len + post.idx + self.forecast_len - 1      # rows written so far

@@ -91,6 +91,11 @@ class BandAdjust:
             return self.step(netG.infer_windows(series, first, count, stride)[:, :Tf], part)
         return self.step_hidden(netG, netG.infer_windows(series, first, count, stride, hidden=True))
 
+    def sweep(self, netG, series, stride=1):
+        """A pipelined pass over window positions (WindowSweep): the generator forward of batch i + 1 runs on a side stream
+        under the band / adjust of batch i."""
+        return WindowSweep(self, netG, series, stride)
+
     def step_hidden(self, netG, hid):
         """_step_all for predictions that exist only as the generator's last hidden buffer `hid` (B, Tf, hidden)."""
         d = self.ds
@@ -196,3 +201,88 @@ class BandAdjust:
         self._rank0_state = W > 1
         self.full_rows = False
         return reals, preds, masks, lower, upper, target
+
+
+class WindowSweep:
+    """The cleaning / prediction sweep as a two-stage pipeline over its batches.  The batches of a sweep are independent
+    through the generator -- it reads the series and its own parameters, nothing a previous batch wrote -- while the band
+    history and the adjust carry chain them on the post-processing side (source/cleaner.py:88-106).  So the generator
+    forward of batch i + 1 is queued on a side stream BEFORE the band / adjust of batch i on the caller's stream:
+    the latency-bound recurrent kernels of one batch then share the chip with the vector-bound band kernel of the other.
+    Same kernels, same arguments, same order per batch: the results do not change.
+
+        sweep = post.sweep(netG, series, stride)
+        for first, count in positions: sweep.push(first, count)
+        sweep.flush()
+
+    TB_CLEAN_PIPELINE side streams (default 3: two forwards and one band / adjust in flight -- the recurrent kernels are
+    latency-bound at one workgroup per CU, two of them fill each other's gaps; 0 = no pipeline); a side stream's next
+    forward waits for the post-processing of its previous batch, so the look-ahead costs that many batches'
+    intermediates, not the sweep's."""
+
+    def __init__(self, post, netG, series, stride=1):
+        self.post, self.netG, self.series, self.stride = post, netG, series, stride
+        depth = int(os.environ.get("TB_CLEAN_PIPELINE", "3"))     # side streams (0: no pipeline, everything on the caller's stream)
+        self.pipelined = series.is_cuda and depth > 0
+        self.depth = max(1, depth)
+        self._side = None
+        self._pending = []                    # forwards queued and not yet post-processed: (tensor, fused?, ready event, side stream)
+        self._done = [None] * self.depth      # post-processing event of the last batch of each side stream
+        self._n = 0
+
+    def _fuse(self, count):
+        p, g = self.post, self.netG
+        Tf = p.ds.forecast_len
+        return (p.fuse_last_layer and g.outseq_len == Tf and count >= Tf - 1 and self.series.is_cuda
+                and ops.dimband_supported(Tf, g.hidden_dim))
+
+    def _forward(self, first, count):
+        fuse = self._fuse(count)
+        out = self.netG.infer_windows(self.series, first, count, self.stride, hidden=fuse)
+        return (out if fuse else out[:, :self.post.ds.forecast_len]), fuse
+
+    def _post(self, out, fuse):
+        return self.post.step_hidden(self.netG, out) if fuse else self.post.step(out)
+
+    def push(self, first, count):
+        if not self.pipelined:
+            return self._post(*self._forward(first, count))
+        dev = self.series.device
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = tuple(torch.cuda.Stream(dev) for _ in range(self.depth))
+            for s_ in self._side:
+                s_.wait_stream(main)           # whatever prepared the series / the parameters on the caller's stream
+        k = self._n % self.depth
+        side = self._side[k]
+        if self._done[k] is not None:
+            side.wait_event(self._done[k])     # look-ahead bound: this stream's previous batch has been post-processed
+        with torch.cuda.stream(side):
+            out, fuse = self._forward(first, count)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        out.record_stream(main)
+        self._pending.append((out, fuse, ready, k))
+        self._n += 1
+        # post-process what is old enough: `depth - 1` forwards stay queued in front of the band / adjust chain
+        res = None
+        while len(self._pending) >= self.depth:
+            res = self._drain()
+        return res
+
+    def _drain(self):
+        out, fuse, ready, k = self._pending.pop(0)
+        main = torch.cuda.current_stream(self.series.device)
+        main.wait_event(ready)
+        res = self._post(out, fuse)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._done[k] = ev
+        return res
+
+    def flush(self):
+        """Post-process the batches still queued (the sweep's tail)."""
+        res = None
+        while self._pending:
+            res = self._drain()
+        return res
