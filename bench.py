@@ -306,6 +306,7 @@ def main():
     def step(i):
         if state["seen"] == nbatches:
             state["it"], state["seen"] = iter(loader), 0
+            trainer.join_post()
             trainer.post.reset()
         batch = next(state["it"])
         state["seen"] += 1
@@ -313,7 +314,7 @@ def main():
         fake = trainer.iteration(batch["encoded"], batch["decoded"], training=True,
                                  n_global=None if part is None else part[1])
         if args.full:
-            trainer.metric.update(*trainer.post.step(fake, part)[:3])
+            trainer.post_process(fake, part)     # band / adjust / scores: on one rank under the next iteration (side stream)
 
     def barrier():
         if world > 1:

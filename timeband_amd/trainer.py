@@ -67,6 +67,9 @@ class TIMEBANDTrainer:
         # stream (ops.Runtime.wgrad_stream); the optimizers join it before they read the gradients
         self.wgrad_overlap = os.environ.get("TB_WGRAD_OVERLAP", "0") == "1"
         self._side = None
+        # band / adjust / scores of a batch on a stream of their own, under the NEXT iteration (one rank; TB_POST_OVERLAP=0: off)
+        self.post_overlap = os.environ.get("TB_POST_OVERLAP", "1") != "0"
+        self._post_stream = None
         self._ones = {}
         self._marks = None      # tools/phase_times.py: list of (name, event on the main stream) per iteration
 
@@ -351,12 +354,44 @@ class TIMEBANDTrainer:
         ops.Runtime.wgrad_overlap = False
         return fake_y.detach()
 
+    def post_process(self, fake_y, part=None, batch_rows=None):
+        """The per-batch tail of trainer.py:202-236: band, adjust, scores -- all on the device.  They read the iteration's
+        fake_y and state of their own and nothing feeds back into the networks, so on one rank they are queued on a side
+        stream and run under the next iteration (the recurrent kernels leave the vector and memory pipes mostly idle); the
+        values are the same.  join_post() before anything reads the scores or resets the state."""
+        vis = self.dashboard is not None and getattr(self.dashboard, "vis_opt", False)
+        side = self.post_overlap and part is None and fake_y.is_cuda and not vis
+        if side:
+            main = torch.cuda.current_stream(fake_y.device)
+            if self._post_stream is None:
+                self._post_stream = torch.cuda.Stream(fake_y.device)
+            self._post_stream.wait_stream(main)
+            fake_y.record_stream(self._post_stream)
+            with torch.cuda.stream(self._post_stream):
+                out = self.post.step(fake_y, part)
+                self.metric.update(out[0], out[1], out[2], full=self.post.full_rows)
+        else:
+            out = self.post.step(fake_y, part)
+            self.metric.update(out[0], out[1], out[2], full=self.post.full_rows)
+        self.idx = self.post.idx
+        if vis:
+            reals, preds, masks, lower, upper, target = out
+            self.dashboard.vis(batch_rows, reals.cpu().numpy(), preds.cpu().numpy(), lower.cpu().numpy(),
+                               upper.cpu().numpy(), target.cpu().numpy())
+        return out
+
+    def join_post(self):
+        """The current stream waits for the post-processing queued so far."""
+        if self._post_stream is not None:
+            torch.cuda.current_stream(self._post_stream.device).wait_stream(self._post_stream)
+
     def train_step(self, epoch: int, dataset, training: bool = True):
         """One pass over `dataset` (any iterable of {"encoded","decoded"} batches); returns the mean
         NMAE like trainer.py:236.  One host sync, at the end.  Data parallel: `dataset` is
         `windowset.loader(batch_size, rank, world)`, whose batches carry this rank's slice and its `part`."""
         if self.optimD is None:
             self.new_epoch()
+        self.join_post()            # the previous pass's tail, before its state is replaced
         self.losses.init_loss()
         self.metric.init_score()
         self.post.restart_pass()
@@ -371,15 +406,11 @@ class TIMEBANDTrainer:
                     fake_y = self.iteration(true_x, true_y, training)
             else:
                 fake_y = self.iteration(true_x, true_y, training, n_global=None if part is None else part[1])
-            reals, preds, masks, lower, upper, target = self.post.step(fake_y, part)
-            full_rows = self.post.full_rows      # every rank holds ALL rows of this batch: only rank 0's sums count
-            self.idx = self.post.idx
-            if self.dashboard is not None and getattr(self.dashboard, "vis_opt", False):
-                self.dashboard.vis(true_y.shape[0], reals.cpu().numpy(), preds.cpu().numpy(), lower.cpu().numpy(),
-                                   upper.cpu().numpy(), target.cpu().numpy())
-            self.metric.update(reals, preds, masks, full=full_rows)
+            # (post.full_rows: every rank holds ALL rows of this batch -- then only rank 0's sums count)
+            self.post_process(fake_y, part, true_y.shape[0])
         if i < 0:
             return float("nan")
+        self.join_post()
         ops.check_errors(dev)
         self.logger.info(desc(training, epoch, self.metric.score(i), self.losses.loss(i)), level=0)
         return self.metric.nmae / (i + 1)
