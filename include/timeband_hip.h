@@ -44,7 +44,9 @@ int tb_prof_read(int kernel_id, int* count_host, double* total_ms_host, double* 
  *           projection is computed inside the recurrent kernel: `gates` is then output only and may be
  *           NULL with train == 0 (TB_FUSE_PROJ=0 in the environment: projection by GEMM for every shape).
  * backward: dy (B,T,H) -> dx (B,T,in) [nullable], dw_ih, dw_hh, db_ih, db_hh [each nullable];
- *           `gates` is consumed (overwritten with the pre-activation gradients).
+ *           `gates` is consumed (overwritten with the pre-activation gradients -- except when all four parameter-gradient
+ *           pointers are null and dx (in <= 32, hidden 128 / 256) is formed inside the kernel: nothing reads them then, and
+ *           the buffer keeps the activated gates).
  *           accumulate != 0: the four parameter gradients are ADDED to what the buffers hold (what
  *           autograd's `.grad +=` does, trainer.py:179-180,193); dx is always overwritten.  The same flag
  *           on tb_linear_bwd (dW, db) and tb_head_bwd (dw, db).

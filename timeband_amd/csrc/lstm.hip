@@ -1017,6 +1017,7 @@ struct BwdArgs {
   int ncl_total;       // clusters of the whole batch (all launches)
   int in_dim;
   int dx_b_begin;      // batch rows before it need no input gradient
+  int store_dg;        // 0: nobody reads dgates afterwards (no weight gradients wanted, dx formed in the kernel): G is left as it is
 };
 
 template <int H, int US, int MT, int DXK = 0>
@@ -1317,12 +1318,13 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       __syncthreads();   // own columns of dhL visible
       STAMP(4);
     }
-    // dgates of this step over the gate stash, in place (after the publish: not on its critical path)
+    // dgates of this step over the gate stash, in place (after the publish: not on its critical path) -- unless no
+    // kernel after this one reads them (the generator phase's pass through D: input gradient only, formed below)
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
       const int e = tid + 256 * n;
       const int row = (e / QPR) & 15, mt = e / (16 * QPR);
-      if (e < NE) {
+      if (e < NE && a.store_dg) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) stgn<UI, 0>(rG, (long)(mt * 16 + row) * rowG + (long)t * 4 * H + g * H + uabs0, dgv[n][g]);
       }
@@ -2059,6 +2061,10 @@ static int lstm_bwd_impl(const float* dy, const float* x, const float* w_ih, con
     a.nclusters = ncl;
     a.timeout_ticks = kTimeoutTicks;
     a.Wih = w_ih; a.in_dim = in_dim; a.dxpart = dxk ? c.dxpart : nullptr; a.dx_b_begin = dx_row_begin; a.ncl_total = ncl_total;
+    // dgates go back to memory for the weight-gradient products (here, or tb_lstm_wgrad later: then the caller asks for the
+    // bias gradients here) and for the dx GEMM; a pass that wants the input gradient only and forms it in the kernel -- the
+    // generator phase's way through D -- leaves `gates` alone (268 MB of stores per launch at cfg2)
+    a.store_dg = (dw_ih || dw_hh || db_ih || db_hh || (want_dx && !dxk)) ? 1 : 0;
     if (c0 == 0) tb_prof_begin(TB_K_LSTM_BWD, s, 4.0 * B * T * (2.0 * in_dim + 6.0 * H));
     rc = launch_bwd(p, a, ncl * p.NCL, s);
     if (rc) return rc;
