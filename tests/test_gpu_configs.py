@@ -565,3 +565,59 @@ def test_pair_loss_gradient_in_one_launch_equals_two(dev, critic):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1][:4], b[1][:4]) and torch.equal(a[2], b[2])
     for x, y in zip(a[3], b[3]):
         assert torch.equal(x, y)
+
+
+def test_post_processing_on_its_own_stream_changes_nothing(dev):
+    """TIMEBANDTrainer.post_process queues band / adjust / scores of a batch on a side stream, where they run under the next
+    iteration (one rank).  Same kernels on the same inputs in the same order: the pass score, the running scores and the
+    band history must equal the in-line run bit for bit."""
+    import bench
+    from timeband_amd.dataset import WindowSet
+    cfg = dict(V=8, NT=4, To=24, Tf=24, H=128, L=1, B=96, N=3000)
+    res = []
+    for overlap in (True, False):
+        np.random.seed(3)
+        ds, trainset, trainer = bench.build(cfg, dev)
+        trainer.post_overlap = overlap
+        np.random.seed(3)
+        loader = WindowSet(ds, trainset.w0, 4 * cfg["B"]).loader(cfg["B"])
+        score = trainer.train_step(0, loader, training=True)
+        torch.cuda.synchronize()
+        res.append((score, trainer.metric.score(3), trainer.post.hist[trainer.post.cur].clone(), trainer.post.last_row.clone(),
+                    [p.detach().clone() for p in trainer.models.netG.parameters()]))
+        assert (trainer._post_stream is not None) == overlap
+    (sa, ma, ha, la, pa), (sb, mb, hb, lb, pb) = res
+    assert sa == sb and ma == mb
+    assert torch.equal(ha, hb) and torch.equal(la, lb)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 4])
+def test_window_sweep_depths_equal(dev, depth, monkeypatch):
+    """postprocess.WindowSweep with 0 (no pipeline), 1, 2 and 4 side streams: identical cleaned series and bands (the default,
+    3, is what test_cfg5_wide_cleaning_vs_oracle runs against the oracle)."""
+    from timeband_amd import synthetic
+    from timeband_amd.cleaner import TIMEBANDCleaner
+    from timeband_amd.dataset import TIMEBANDDataset
+    from timeband_amd.model import TIMEBANDModel
+    from timeband_amd.utils.logger import NullLogger
+    V, To, Tf, H, L, B, N = 40, 12, 12, 64, 1, 30, 400
+    values = synthetic.make_series(N, V, seed=9)
+    tfeat = synthetic.time_features(N + Tf)
+    core = dict(logger=NullLogger(), device=dev, batch_size=B, observed_len=To, forecast_len=Tf, directory="",
+                data_name="synthetic")
+    ds = TIMEBANDDataset.from_arrays(values, tfeat, {**core, "stride": 1, "split_rate": 0.9, "min_valid_scale": 2,
+                                                     "sliding_step": 0})
+    torch.manual_seed(11)
+    netD, netG = make_nets(V, V + tfeat.shape[1], To, Tf, H, L, dev)
+    holder = TIMEBANDModel.__new__(TIMEBANDModel)
+    holder.netG, holder.netD = netG, None
+    cfg = {**core, "band_width": 1.0, "missing_gamma": 0.2, "anomaly_gamma": 0.3}
+    full = ds.prepare_dataset(split=False)
+    want = [t.clone() for t in TIMEBANDCleaner(cfg, ds, holder).clean_arrays(full.loader(B))]
+    monkeypatch.setenv("TB_CLEAN_PIPELINE", str(depth))
+    got = TIMEBANDCleaner(cfg, ds, holder).clean_arrays(full.loader(B))
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert torch.equal(torch.nan_to_num(a, nan=1e30), torch.nan_to_num(b, nan=1e30))
